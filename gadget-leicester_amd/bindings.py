@@ -1,0 +1,326 @@
+"""ctypes bindings of libghip.so (include/ghip.h).  Thin: every method is one C call.
+
+No CPU fallback: constructing ForcePath without the library or without a GPU raises.
+"""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+
+_pkg = importlib.import_module(__package__)
+
+# enum ghip_field
+(F_POS, F_VEL, F_MASS, F_TYPE, F_OLDACC, F_HSML, F_TIMEBIN, F_TI_BEGSTEP, F_VELPRED, F_ENTROPY,
+ F_DTENTROPY, F_GRAVACCEL, F_GRAVCOST, F_NUMNGB, F_DENSITY, F_DHSMLFAC, F_DIVVEL, F_CURLVEL,
+ F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_COUNT) = range(22)
+
+_FIELD_INFO = {  # gas-sized?, ncomp, is int
+    F_POS: (0, 3, 0), F_VEL: (0, 3, 0), F_MASS: (0, 1, 0), F_TYPE: (0, 1, 1), F_OLDACC: (0, 1, 0),
+    F_HSML: (0, 1, 0), F_TIMEBIN: (0, 1, 1), F_TI_BEGSTEP: (0, 1, 1), F_VELPRED: (1, 3, 0),
+    F_ENTROPY: (1, 1, 0), F_DTENTROPY: (1, 1, 0), F_GRAVACCEL: (0, 3, 0), F_GRAVCOST: (0, 1, 1),
+    F_NUMNGB: (1, 1, 0), F_DENSITY: (1, 1, 0), F_DHSMLFAC: (1, 1, 0), F_DIVVEL: (1, 1, 0),
+    F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0)}
+
+WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD = 0, 1, 2
+EN = 64
+
+GHIP_ERRORS = {-90001: "GHIP_EHIP", -90002: "GHIP_EINVAL", -90003: "GHIP_ENOMEM",
+               -90004: "GHIP_ENOCONV", -90005: "GHIP_ENODEVICE"}
+
+
+class Layout(C.Structure):
+    _fields_ = [(k, C.c_int) for k in (
+        "p_stride", "p_pos", "p_vel", "p_mass", "p_gravaccel", "p_oldacc", "p_gravcost",
+        "p_ti_begstep", "p_type", "p_timebin", "p_hsml", "p_numngb",
+        "s_stride", "s_entropy", "s_pressure", "s_velpred", "s_maxsignalvel", "s_density",
+        "s_dtentropy", "s_hydroaccel", "s_dhsmlfac", "s_divvel", "s_curlvel", "s_hsml",
+        "s_numngb")]
+
+
+class GravParams(C.Structure):
+    _fields_ = [("ErrTolTheta", C.c_double), ("ErrTolForceAcc", C.c_double),
+                ("ForceSoftening", C.c_double * 6), ("BoxSize", C.c_double),
+                ("periodic", C.c_int), ("unequal_softenings", C.c_int),
+                ("Rcut", C.c_double), ("Asmth", C.c_double)]
+
+
+class DensParams(C.Structure):
+    _fields_ = [("DesNumNgb", C.c_double), ("MaxNumNgbDeviation", C.c_double),
+                ("MinGasHsml", C.c_double), ("BoxSize", C.c_double), ("periodic", C.c_int),
+                ("Ti_Current", C.c_int), ("Timebase_interval", C.c_double), ("MaxIter", C.c_int)]
+
+
+class HydroParams(C.Structure):
+    _fields_ = [("ArtBulkViscConst", C.c_double), ("BoxSize", C.c_double), ("periodic", C.c_int),
+                ("ComovingIntegrationOn", C.c_int), ("hubble_a2", C.c_double),
+                ("fac_mu", C.c_double), ("fac_vsic_fix", C.c_double),
+                ("Timebase_interval", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("grav_interactions", C.c_longlong), ("grav_targets", C.c_longlong),
+                ("ewald_interactions", C.c_longlong), ("dens_neighbours", C.c_longlong),
+                ("dens_target_evals", C.c_longlong), ("dens_iterations", C.c_int),
+                ("hydro_pairs", C.c_longlong), ("hydro_targets", C.c_longlong),
+                ("tree_nodes", C.c_int), ("gastree_nodes", C.c_int),
+                ("ms_tree", C.c_float), ("ms_grav", C.c_float), ("ms_ewald", C.c_float),
+                ("ms_dens", C.c_float), ("ms_hmax", C.c_float), ("ms_hydro", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class GhipError(RuntimeError):
+    def __init__(self, code, msg):
+        self.code = code
+        RuntimeError.__init__(self, "%s (%d): %s" % (GHIP_ERRORS.get(code, "GHIP_E?"), code, msg))
+
+
+_LIB = None
+
+EXPORTS = [
+    "ghip_create", "ghip_destroy", "ghip_last_error", "ghip_version", "ghip_set_counts",
+    "ghip_set_field", "ghip_get_field", "ghip_upload_aos", "ghip_download_aos", "ghip_set_active",
+    "ghip_set_shard", "ghip_tree_build", "ghip_ewald_init", "ghip_ewald_get_table", "ghip_gravity",
+    "ghip_gravity_ext", "ghip_gravity_finish", "ghip_gravity_direct", "ghip_density",
+    "ghip_update_hmax", "ghip_hydro", "ghip_density_evaluate", "ghip_ngb_treefind",
+    "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
+    "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(_pkg.lib_path())
+        vp = C.c_void_p
+        L.ghip_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ghip_destroy.argtypes = [vp]
+        L.ghip_destroy.restype = None
+        L.ghip_last_error.argtypes = [vp]
+        L.ghip_last_error.restype = C.c_char_p
+        L.ghip_version.restype = C.c_char_p
+        L.ghip_set_counts.argtypes = [vp, C.c_int, C.c_int]
+        L.ghip_set_field.argtypes = [vp, C.c_int, vp]
+        L.ghip_get_field.argtypes = [vp, C.c_int, vp]
+        L.ghip_upload_aos.argtypes = [vp, vp, vp, C.POINTER(Layout), C.c_int, C.c_int]
+        L.ghip_download_aos.argtypes = [vp, vp, vp, C.POINTER(Layout), C.c_int, C.c_int, C.c_int]
+        L.ghip_set_active.argtypes = [vp, vp, C.c_int]
+        L.ghip_set_shard.argtypes = [vp, C.c_int, C.c_int]
+        L.ghip_tree_build.argtypes = [vp, vp, vp, C.c_double, vp]
+        L.ghip_ewald_init.argtypes = [vp, C.c_double]
+        L.ghip_ewald_get_table.argtypes = [vp, vp]
+        L.ghip_gravity.argtypes = [vp, C.POINTER(GravParams), C.c_int]
+        L.ghip_gravity_ext.argtypes = [vp, C.POINTER(GravParams), C.c_int, C.c_int, vp, vp, vp,
+                                       vp, vp]
+        L.ghip_gravity_finish.argtypes = [vp, C.c_double]
+        L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
+        L.ghip_density.argtypes = [vp, C.POINTER(DensParams)]
+        L.ghip_update_hmax.argtypes = [vp]
+        L.ghip_hydro.argtypes = [vp, C.POINTER(HydroParams)]
+        L.ghip_density_evaluate.argtypes = [vp, C.POINTER(DensParams), C.c_int, C.c_double, vp]
+        L.ghip_ngb_treefind.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.c_double, vp,
+                                        C.c_int, C.POINTER(C.c_int)]
+        L.ghip_peano_hilbert_keys.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]
+        L.ghip_morton_keys.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]
+        L.ghip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.ghip_tree_dump.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, vp]
+        L.ghip_stream.argtypes = [vp]
+        L.ghip_stream.restype = vp
+        L.ghip_sync.argtypes = [vp]
+        L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ghip_shard_pack.argtypes = [vp, C.c_int, vp]
+        L.ghip_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ForcePath:
+    """One device context (one per process / GPU)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.ghip_create(int(device), C.byref(h))
+        if rc != 0:
+            raise GhipError(rc, "ghip_create(device=%d) failed: no usable GPU; this package has "
+                                "no CPU path" % device)
+        self.h = h
+        self.n = 0
+        self.ngas = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ghip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GhipError(rc, self.L.ghip_last_error(self.h).decode())
+
+    # ---- data ----
+    def set_counts(self, n, ngas):
+        self._chk(self.L.ghip_set_counts(self.h, int(n), int(ngas)))
+        self.n, self.ngas = int(n), int(ngas)
+
+    def _shape(self, field):
+        gas, ncomp, isint = _FIELD_INFO[field]
+        cnt = self.ngas if gas else self.n
+        return ((cnt, 3) if ncomp == 3 else (cnt,)), (np.int32 if isint else np.float64)
+
+    def set_field(self, field, arr):
+        shape, dt = self._shape(field)
+        a = np.ascontiguousarray(arr, dtype=dt)
+        if a.shape != shape:
+            raise ValueError("field %d: expected shape %s, got %s" % (field, shape, a.shape))
+        self._chk(self.L.ghip_set_field(self.h, field, _ptr(a)))
+
+    def get_field(self, field):
+        shape, dt = self._shape(field)
+        a = np.zeros(shape, dtype=dt)
+        self._chk(self.L.ghip_get_field(self.h, field, _ptr(a)))
+        return a
+
+    def upload_aos(self, P, SphP, layout):
+        n, ng = len(P), (0 if SphP is None else len(SphP))
+        self._chk(self.L.ghip_upload_aos(self.h, _ptr(P), _ptr(SphP) if ng else None,
+                                         C.byref(layout), n, ng))
+        self.n, self.ngas = n, ng
+
+    def download_aos(self, P, SphP, layout, gravity=True, density=True, hydro=True):
+        self._chk(self.L.ghip_download_aos(self.h, _ptr(P), _ptr(SphP) if self.ngas else None,
+                                           C.byref(layout), int(gravity), int(density),
+                                           int(hydro)))
+
+    def set_active(self, idx=None):
+        if idx is None:
+            self._chk(self.L.ghip_set_active(self.h, None, 0))
+        else:
+            a = np.ascontiguousarray(idx, dtype=np.int32)
+            self._active_keep = a
+            self._chk(self.L.ghip_set_active(self.h, _ptr(a), len(a)))
+
+    def set_shard(self, rank, nranks):
+        self._chk(self.L.ghip_set_shard(self.h, int(rank), int(nranks)))
+
+    # ---- the path ----
+    def tree_build(self, corner, center, dlen, force_softening):
+        c0 = np.ascontiguousarray(corner, dtype=np.float64)
+        c1 = np.ascontiguousarray(center, dtype=np.float64)
+        sf = np.ascontiguousarray(force_softening, dtype=np.float64)
+        self._chk(self.L.ghip_tree_build(self.h, _ptr(c0), _ptr(c1), float(dlen), _ptr(sf)))
+
+    def ewald_init(self, boxsize):
+        self._chk(self.L.ghip_ewald_init(self.h, float(boxsize)))
+
+    def ewald_table(self):
+        t = np.zeros((3, EN + 1, EN + 1, EN + 1))
+        self._chk(self.L.ghip_ewald_get_table(self.h, _ptr(t)))
+        return t
+
+    def gravity(self, params, walk=WALK_NEWTON):
+        self._chk(self.L.ghip_gravity(self.h, C.byref(params), int(walk)))
+
+    def gravity_ext(self, params, pos, ptype, oldacc, walk=WALK_NEWTON):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        ptype = np.ascontiguousarray(ptype, dtype=np.int32)
+        oldacc = np.ascontiguousarray(oldacc, dtype=np.float64)
+        nt = len(pos)
+        acc = np.zeros((nt, 3))
+        nint = np.zeros(nt, np.int32)
+        self._chk(self.L.ghip_gravity_ext(self.h, C.byref(params), int(walk), nt, _ptr(pos),
+                                          _ptr(ptype), _ptr(oldacc), _ptr(acc), _ptr(nint)))
+        return acc, nint
+
+    def gravity_finish(self, G):
+        self._chk(self.L.ghip_gravity_finish(self.h, float(G)))
+
+    def gravity_direct(self, params):
+        self._chk(self.L.ghip_gravity_direct(self.h, C.byref(params)))
+
+    def density(self, params):
+        self._chk(self.L.ghip_density(self.h, C.byref(params)))
+
+    def update_hmax(self):
+        self._chk(self.L.ghip_update_hmax(self.h))
+
+    def hydro(self, params):
+        self._chk(self.L.ghip_hydro(self.h, C.byref(params)))
+
+    def density_evaluate(self, params, target, h):
+        out = np.zeros(7)
+        self._chk(self.L.ghip_density_evaluate(self.h, C.byref(params), int(target), float(h),
+                                               _ptr(out)))
+        return out
+
+    def ngb_treefind(self, center, hsml, pairs, periodic, boxsize, cap=None):
+        c = np.ascontiguousarray(center, dtype=np.float64)
+        cap = self.ngas if cap is None else cap
+        buf = np.zeros(max(cap, 1), np.int32)
+        nf = C.c_int(0)
+        self._chk(self.L.ghip_ngb_treefind(self.h, _ptr(c), float(hsml), int(pairs),
+                                           int(periodic), float(boxsize), _ptr(buf), int(cap),
+                                           C.byref(nf)))
+        return buf[:min(nf.value, cap)].copy(), nf.value
+
+    def peano_hilbert_keys(self, x, y, z, bits=21):
+        x, y, z = [np.ascontiguousarray(a, dtype=np.int32) for a in (x, y, z)]
+        k = np.zeros(len(x), np.uint64)
+        self._chk(self.L.ghip_peano_hilbert_keys(self.h, len(x), _ptr(x), _ptr(y), _ptr(z),
+                                                 int(bits), _ptr(k)))
+        return k
+
+    def morton_keys(self, x, y, z, bits=21):
+        x, y, z = [np.ascontiguousarray(a, dtype=np.int32) for a in (x, y, z)]
+        k = np.zeros(len(x), np.uint64)
+        self._chk(self.L.ghip_morton_keys(self.h, len(x), _ptr(x), _ptr(y), _ptr(z), int(bits),
+                                          _ptr(k)))
+        return k
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.ghip_get_stats(self.h, C.byref(s)))
+        return s.asdict()
+
+    def tree_dump(self, which=0):
+        ne = C.c_int(0)
+        self._chk(self.L.ghip_tree_dump(self.h, which, C.byref(ne), None, None, None, None, None))
+        ne = ne.value
+        npart = self.ngas if which else self.n
+        out = dict(xm=np.zeros((ne, 4)), cl=np.zeros((ne, 4)), lk=np.zeros((ne, 4), np.int32),
+                   aux=np.zeros(ne), perm=np.zeros(npart, np.int32))
+        n2 = C.c_int(0)
+        self._chk(self.L.ghip_tree_dump(self.h, which, C.byref(n2), _ptr(out["xm"]),
+                                        _ptr(out["cl"]), _ptr(out["lk"]), _ptr(out["aux"]),
+                                        _ptr(out["perm"])))
+        return out
+
+    def sync(self):
+        self._chk(self.L.ghip_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.ghip_stream(self.h)
+
+    # ---- multi-GPU shard exchange helpers (device pointers, e.g. torch tensors' data_ptr()) ----
+    def shard_count(self, gas):
+        per = C.c_int(0)
+        mine = C.c_int(0)
+        self._chk(self.L.ghip_shard_count(self.h, int(gas), C.byref(per), C.byref(mine)))
+        return per.value, mine.value
+
+    def shard_pack(self, group, dev_ptr):
+        self._chk(self.L.ghip_shard_pack(self.h, int(group), C.c_void_p(dev_ptr)))
+
+    def shard_unpack(self, group, dev_ptr, nranks):
+        self._chk(self.L.ghip_shard_unpack(self.h, int(group), C.c_void_p(dev_ptr), int(nranks)))

@@ -1,0 +1,575 @@
+// ghip_api.hip -- C-ABI entry points: lifetime, particle data movement, introspection.
+// See include/ghip.h for what each entry point replaces in the reference.
+#include <cstdarg>
+
+#include "ghip_internal.h"
+
+int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if(ctx)
+    ctx->err = buf;
+  return code;
+}
+
+int ghip_ensure(ghip_ctx *ctx, DevBuf &b, size_t bytes)
+{
+  if(bytes == 0)
+    bytes = 8;
+  if(b.cap >= bytes)
+    return GHIP_OK;
+  // grow with slack so that per-step size jitter does not reallocate
+  size_t want = bytes + bytes / 8 + 256;
+  if(b.p)
+    {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+  hipError_t e = hipMalloc(&b.p, want);
+  if(e != hipSuccess)
+    {
+      b.p = nullptr;
+      return ghip_fail(ctx, GHIP_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+  b.cap = want;
+  return GHIP_OK;
+}
+
+static void free_buf(DevBuf &b)
+{
+  if(b.p)
+    (void) hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+extern "C" const char *ghip_version(void)
+{
+  return "ghip 0.1 (gfx950)";
+}
+
+extern "C" int ghip_create(int device, ghip_ctx **out)
+{
+  if(!out)
+    return GHIP_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return GHIP_ENODEVICE;
+  if(device < 0 || device >= ndev)
+    return GHIP_ENODEVICE;
+  ghip_ctx *ctx = new(std::nothrow) ghip_ctx();
+  if(!ctx)
+    return GHIP_ENOMEM;
+  ctx->device = device;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if(hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_ENODEVICE;
+    }
+  for(int i = 0; i < 12; i++)
+    if(hipEventCreate(&ctx->ev[i]) != hipSuccess)
+      {
+        delete ctx;
+        return GHIP_EHIP;
+      }
+  ctx->ev_ready = true;
+  // make every event "recorded" so that elapsed-time queries never fault
+  for(int i = 0; i < 12; i++)
+    (void) hipEventRecord(ctx->ev[i], ctx->stream);
+  (void) hipStreamSynchronize(ctx->stream);
+  *out = ctx;
+  return GHIP_OK;
+}
+
+static void free_tree(TreeDev &t)
+{
+  DevBuf *bs[] = {&t.key, &t.skey, &t.idx, &t.perm, &t.iperm, &t.cpl, &t.cnt, &t.nb,
+                  &t.xm,  &t.cl,   &t.lk,  &t.aux};
+  for(DevBuf *b : bs)
+    free_buf(*b);
+}
+
+extern "C" void ghip_destroy(ghip_ctx *ctx)
+{
+  if(!ctx)
+    return;
+  (void) hipSetDevice(ctx->device);
+  if(ctx->stream)
+    (void) hipStreamSynchronize(ctx->stream);
+  for(int i = 0; i < GHIP_F_COUNT; i++)
+    free_buf(ctx->f[i]);
+  DevBuf *bs[] = {&ctx->stage,  &ctx->aosP,   &ctx->aosS,    &ctx->sx,      &ctx->sy,
+                  &ctx->sz,     &ctx->ssoft,  &ctx->soldacc, &ctx->gp,      &ctx->gq,
+                  &ctx->dleft,  &ctx->dright, &ctx->drho,    &ctx->dnumngb, &ctx->ddhsml,
+                  &ctx->ddivv,  &ctx->drot,   &ctx->dflags,  &ctx->dtgt_a,  &ctx->dtgt_b,
+                  &ctx->act_host_idx, &ctx->tg_grav, &ctx->tg_gas, &ctx->tax, &ctx->tay,
+                  &ctx->taz,    &ctx->tcost,  &ctx->ewtab,   &ctx->srtab,   &ctx->cubtmp,
+                  &ctx->counters};
+  for(DevBuf *b : bs)
+    free_buf(*b);
+  free_tree(ctx->gt);
+  free_tree(ctx->st);
+  if(ctx->pinned)
+    (void) hipHostFree(ctx->pinned);
+  if(ctx->ev_ready)
+    for(int i = 0; i < 12; i++)
+      (void) hipEventDestroy(ctx->ev[i]);
+  if(ctx->stream)
+    (void) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *ghip_last_error(const ghip_ctx *ctx)
+{
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+extern "C" void *ghip_stream(ghip_ctx *ctx)
+{
+  return ctx ? (void *) ctx->stream : nullptr;
+}
+
+extern "C" int ghip_sync(ghip_ctx *ctx)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// field table
+// ---------------------------------------------------------------------------------------------
+struct FieldInfo
+{
+  int gas;    // 1: sized ngas, 0: sized numpart
+  int ncomp;  // 1 or 3
+  int isint;
+};
+
+static const FieldInfo kField[GHIP_F_COUNT] = {
+  /* POS */ {0, 3, 0},        /* VEL */ {0, 3, 0},       /* MASS */ {0, 1, 0},
+  /* TYPE */ {0, 1, 1},       /* OLDACC */ {0, 1, 0},    /* HSML */ {0, 1, 0},
+  /* TIMEBIN */ {0, 1, 1},    /* TI_BEGSTEP */ {0, 1, 1}, /* VELPRED */ {1, 3, 0},
+  /* ENTROPY */ {1, 1, 0},    /* DTENTROPY */ {1, 1, 0}, /* GRAVACCEL */ {0, 3, 0},
+  /* GRAVCOST */ {0, 1, 1},   /* NUMNGB */ {1, 1, 0},    /* DENSITY */ {1, 1, 0},
+  /* DHSMLFAC */ {1, 1, 0},   /* DIVVEL */ {1, 1, 0},    /* CURLVEL */ {1, 1, 0},
+  /* PRESSURE */ {1, 1, 0},   /* HYDROACCEL */ {1, 3, 0}, /* MAXSIGNALVEL */ {1, 1, 0}};
+
+static size_t field_count(const ghip_ctx *ctx, int f)
+{
+  return (size_t) (kField[f].gas ? ctx->ngas : ctx->n);
+}
+
+static size_t field_bytes(const ghip_ctx *ctx, int f)
+{
+  return field_count(ctx, f) * kField[f].ncomp * (kField[f].isint ? 4 : 8);
+}
+
+extern "C" int ghip_set_counts(ghip_ctx *ctx, int numpart, int ngas)
+{
+  if(!ctx || numpart < 0 || ngas < 0 || ngas > numpart)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_counts: need 0 <= ngas <= numpart");
+  HIPCHK(hipSetDevice(ctx->device));
+  bool changed = (numpart != ctx->n || ngas != ctx->ngas);
+  ctx->n = numpart;
+  ctx->ngas = ngas;
+  for(int f = 0; f < GHIP_F_COUNT; f++)
+    {
+      size_t before = ctx->f[f].cap;
+      GCHK(ghip_ensure(ctx, ctx->f[f], field_bytes(ctx, f)));
+      if(ctx->f[f].cap != before)
+        HIPCHK(hipMemsetAsync(ctx->f[f].p, 0, ctx->f[f].cap, ctx->stream));
+    }
+  if(changed)
+    {
+      ctx->gt.built = false;
+      ctx->st.built = false;
+      ctx->nactive = -1;
+      ctx->lists_dirty = true;
+    }
+  return GHIP_OK;
+}
+
+// [n][ncomp] (host layout, in `stage`) <-> SoA with pitch n (device layout)
+template <class T>
+__global__ void k_aos_to_soa(size_t n, int ncomp, const T *__restrict__ src, T *__restrict__ dst)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  for(int c = 0; c < ncomp; c++)
+    dst[(size_t) c * n + i] = src[i * ncomp + c];
+}
+
+template <class T>
+__global__ void k_soa_to_aos(size_t n, int ncomp, const T *__restrict__ src, T *__restrict__ dst)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  for(int c = 0; c < ncomp; c++)
+    dst[i * ncomp + c] = src[(size_t) c * n + i];
+}
+
+extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
+{
+  if(!ctx || field < 0 || field >= GHIP_F_COUNT)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_field: bad field %d", field);
+  size_t cnt = field_count(ctx, field), bytes = field_bytes(ctx, field);
+  if(cnt == 0)
+    return GHIP_OK;
+  if(!host)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_field: null host pointer");
+  hipStream_t st = ctx->stream;
+  if(kField[field].ncomp == 1)
+    HIPCHK(hipMemcpyAsync(ctx->f[field].p, host, bytes, hipMemcpyHostToDevice, st));
+  else
+    {
+      GCHK(ghip_ensure(ctx, ctx->stage, bytes));
+      HIPCHK(hipMemcpyAsync(ctx->stage.p, host, bytes, hipMemcpyHostToDevice, st));
+      k_aos_to_soa<double><<<cdiv((long long) cnt, 256), 256, 0, st>>>(
+        cnt, 3, P<double>(ctx->stage), P<double>(ctx->f[field]));
+      HIPCHK(hipGetLastError());
+    }
+  HIPCHK(hipStreamSynchronize(st));
+  if(field == GHIP_F_POS || field == GHIP_F_MASS || field == GHIP_F_TYPE)
+    {
+      ctx->gt.built = false;
+      ctx->st.built = false;
+    }
+  return GHIP_OK;
+}
+
+extern "C" int ghip_get_field(ghip_ctx *ctx, int field, void *host)
+{
+  if(!ctx || field < 0 || field >= GHIP_F_COUNT)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_get_field: bad field %d", field);
+  size_t cnt = field_count(ctx, field), bytes = field_bytes(ctx, field);
+  if(cnt == 0)
+    return GHIP_OK;
+  if(!host)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_get_field: null host pointer");
+  hipStream_t st = ctx->stream;
+  if(kField[field].ncomp == 1)
+    HIPCHK(hipMemcpyAsync(host, ctx->f[field].p, bytes, hipMemcpyDeviceToHost, st));
+  else
+    {
+      GCHK(ghip_ensure(ctx, ctx->stage, bytes));
+      k_soa_to_aos<double><<<cdiv((long long) cnt, 256), 256, 0, st>>>(
+        cnt, 3, P<double>(ctx->f[field]), P<double>(ctx->stage));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(host, ctx->stage.p, bytes, hipMemcpyDeviceToHost, st));
+    }
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole-record (AoS) path: the drop-in boundary under accel.c
+// ---------------------------------------------------------------------------------------------
+__global__ void k_unpack_f64(size_t n, const char *__restrict__ rec, int stride, int off, int ncomp,
+                             double *__restrict__ dst)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const double *src = reinterpret_cast<const double *>(rec + i * (size_t) stride + off);
+  for(int c = 0; c < ncomp; c++)
+    dst[(size_t) c * n + i] = src[c];
+}
+
+__global__ void k_unpack_i16(size_t n, const char *__restrict__ rec, int stride, int off,
+                             int *__restrict__ dst)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = (int) *reinterpret_cast<const short *>(rec + i * (size_t) stride + off);
+}
+
+__global__ void k_unpack_i32(size_t n, const char *__restrict__ rec, int stride, int off,
+                             int *__restrict__ dst)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = *reinterpret_cast<const int *>(rec + i * (size_t) stride + off);
+}
+
+__global__ void k_pack_f64(size_t n, char *__restrict__ rec, int stride, int off, int ncomp,
+                           const double *__restrict__ src)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  double *dst = reinterpret_cast<double *>(rec + i * (size_t) stride + off);
+  for(int c = 0; c < ncomp; c++)
+    dst[c] = src[(size_t) c * n + i];
+}
+
+__global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, int off,
+                                const int *__restrict__ src)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    *reinterpret_cast<float *>(rec + i * (size_t) stride + off) = (float) src[i];  // P[].GravCost
+}
+
+#define UNPACK64(cnt, img, stride, off, ncomp, fld)                                           \
+  do                                                                                          \
+    {                                                                                         \
+      if((off) >= 0 && (cnt) > 0)                                                             \
+        k_unpack_f64<<<cdiv((long long) (cnt), 256), 256, 0, st>>>(                           \
+          (size_t) (cnt), (const char *) (img), (stride), (off), (ncomp), P<double>(ctx->f[fld])); \
+    }                                                                                         \
+  while(0)
+
+#define PACK64(cnt, img, stride, off, ncomp, fld)                                             \
+  do                                                                                          \
+    {                                                                                         \
+      if((off) >= 0 && (cnt) > 0)                                                             \
+        k_pack_f64<<<cdiv((long long) (cnt), 256), 256, 0, st>>>(                             \
+          (size_t) (cnt), (char *) (img), (stride), (off), (ncomp), P<double>(ctx->f[fld]));  \
+    }                                                                                         \
+  while(0)
+
+extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, const ghip_layout *lay,
+                               int numpart, int ngas)
+{
+  if(!ctx || !lay || numpart < 0 || ngas < 0 || ngas > numpart || (numpart > 0 && !Pp) ||
+     (ngas > 0 && !Sp))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad arguments");
+  if(lay->p_stride <= 0 || (ngas > 0 && lay->s_stride <= 0))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad strides");
+  if((lay->p_hsml >= 0) == (lay->s_hsml >= 0) && ngas > 0)
+    return ghip_fail(ctx, GHIP_EINVAL,
+                     "ghip_upload_aos: exactly one of p_hsml / s_hsml must be set (PPP macro)");
+  GCHK(ghip_set_counts(ctx, numpart, ngas));
+  hipStream_t st = ctx->stream;
+  size_t n = (size_t) numpart, ng = (size_t) ngas;
+  if(n == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, ctx->aosP, n * lay->p_stride));
+  HIPCHK(hipMemcpyAsync(ctx->aosP.p, Pp, n * lay->p_stride, hipMemcpyHostToDevice, st));
+  if(ng > 0)
+    {
+      GCHK(ghip_ensure(ctx, ctx->aosS, ng * lay->s_stride));
+      HIPCHK(hipMemcpyAsync(ctx->aosS.p, Sp, ng * lay->s_stride, hipMemcpyHostToDevice, st));
+    }
+  const void *ip = ctx->aosP.p, *is = ctx->aosS.p;
+  UNPACK64(n, ip, lay->p_stride, lay->p_pos, 3, GHIP_F_POS);
+  UNPACK64(n, ip, lay->p_stride, lay->p_vel, 3, GHIP_F_VEL);
+  UNPACK64(n, ip, lay->p_stride, lay->p_mass, 1, GHIP_F_MASS);
+  UNPACK64(n, ip, lay->p_stride, lay->p_oldacc, 1, GHIP_F_OLDACC);
+  if(lay->p_type >= 0)
+    k_unpack_i16<<<cdiv((long long) n, 256), 256, 0, st>>>(n, (const char *) ip, lay->p_stride,
+                                                           lay->p_type, P<int>(ctx->f[GHIP_F_TYPE]));
+  if(lay->p_timebin >= 0)
+    k_unpack_i16<<<cdiv((long long) n, 256), 256, 0, st>>>(
+      n, (const char *) ip, lay->p_stride, lay->p_timebin, P<int>(ctx->f[GHIP_F_TIMEBIN]));
+  if(lay->p_ti_begstep >= 0)
+    k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
+      n, (const char *) ip, lay->p_stride, lay->p_ti_begstep, P<int>(ctx->f[GHIP_F_TI_BEGSTEP]));
+  if(lay->p_hsml >= 0)
+    UNPACK64(n, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
+  if(ng > 0)
+    {
+      if(lay->s_hsml >= 0)
+        UNPACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);  // first ngas entries
+      UNPACK64(ng, is, lay->s_stride, lay->s_velpred, 3, GHIP_F_VELPRED);
+      UNPACK64(ng, is, lay->s_stride, lay->s_entropy, 1, GHIP_F_ENTROPY);
+      UNPACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
+      UNPACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
+      UNPACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
+      UNPACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
+      UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
+      UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
+    }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  ctx->gt.built = false;
+  ctx->st.built = false;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
+                                 int want_gravity, int want_density, int want_hydro)
+{
+  if(!ctx || !lay)
+    return GHIP_EINVAL;
+  size_t n = (size_t) ctx->n, ng = (size_t) ctx->ngas;
+  if(n == 0)
+    return GHIP_OK;
+  if(!Pp || (ng > 0 && !Sp))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_download_aos: null record pointers");
+  if(ctx->aosP.cap < n * lay->p_stride || (ng > 0 && ctx->aosS.cap < ng * lay->s_stride))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_download_aos: no device image (call ghip_upload_aos)");
+  hipStream_t st = ctx->stream;
+  void *ip = ctx->aosP.p, *is = ctx->aosS.p;
+  bool touchP = false, touchS = false;
+  if(want_gravity)
+    {
+      PACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
+      PACK64(n, ip, lay->p_stride, lay->p_oldacc, 1, GHIP_F_OLDACC);
+      if(lay->p_gravcost >= 0)
+        k_pack_cost_f32<<<cdiv((long long) n, 256), 256, 0, st>>>(
+          n, (char *) ip, lay->p_stride, lay->p_gravcost, P<int>(ctx->f[GHIP_F_GRAVCOST]));
+      touchP = true;
+    }
+  if(want_density && ng > 0)
+    {
+      if(lay->p_hsml >= 0)
+        {
+          PACK64(ng, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
+          PACK64(ng, ip, lay->p_stride, lay->p_numngb, 1, GHIP_F_NUMNGB);
+          touchP = true;
+        }
+      else
+        {
+          PACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);
+          PACK64(ng, is, lay->s_stride, lay->s_numngb, 1, GHIP_F_NUMNGB);
+        }
+      PACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
+      PACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
+      PACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
+      PACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
+      PACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
+      touchS = true;
+    }
+  if(want_hydro && ng > 0)
+    {
+      PACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
+      PACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
+      PACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
+      touchS = true;
+    }
+  HIPCHK(hipGetLastError());
+  if(touchP)
+    HIPCHK(hipMemcpyAsync(Pp, ip, n * lay->p_stride, hipMemcpyDeviceToHost, st));
+  if(touchS)
+    HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// active list / shard / tree / stats
+// ---------------------------------------------------------------------------------------------
+extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
+{
+  if(!ctx || nactive < 0)
+    return GHIP_EINVAL;
+  if(!idx)
+    {
+      if(nactive != 0 && nactive != ctx->n)
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_active: NULL list means all particles");
+      ctx->nactive = (nactive == 0 && ctx->n != 0) ? -1 : -1;
+      ctx->lists_dirty = true;
+      return GHIP_OK;
+    }
+  for(int a = 0; a < nactive; a++)
+    if(idx[a] < 0 || idx[a] >= ctx->n)
+      return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_active: index %d out of range", idx[a]);
+  GCHK(ghip_ensure(ctx, ctx->act_host_idx, (size_t) nactive * 4));
+  if(nactive > 0)
+    {
+      HIPCHK(hipMemcpyAsync(ctx->act_host_idx.p, idx, (size_t) nactive * 4, hipMemcpyHostToDevice,
+                            ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  ctx->nactive = nactive;
+  ctx->lists_dirty = true;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks)
+{
+  if(!ctx || nranks < 1 || rank < 0 || rank >= nranks)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_shard: need 0 <= rank < nranks");
+  ctx->shard_rank = rank;
+  ctx->shard_n = nranks;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_tree_build(ghip_ctx *ctx, const double corner[3], const double center[3],
+                               double len, const double soft[6])
+{
+  if(!ctx || !corner || !center || !soft || !(len > 0))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_build: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  for(int j = 0; j < 3; j++)
+    {
+      ctx->corner[j] = corner[j];
+      ctx->center[j] = center[j];
+    }
+  ctx->dlen = len;
+  for(int j = 0; j < 6; j++)
+    ctx->soft[j] = soft[j];
+  return ghip_tree_build_impl(ctx);
+}
+
+extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
+{
+  ghip_ctx *ctx = const_cast<ghip_ctx *>(cctx);
+  if(!ctx || !out)
+    return GHIP_EINVAL;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ghip_stats &S = ctx->stats;
+  if(ctx->counters.p)
+    {
+      unsigned long long c[8];
+      HIPCHK(hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+      S.grav_interactions = (long long) c[0];
+      S.ewald_interactions = (long long) c[1];
+      S.dens_neighbours = (long long) c[4];
+      S.hydro_pairs = (long long) c[6];
+    }
+  auto el = [&](int a, int b) {
+    float ms = 0;
+    if(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess)
+      ms = 0;
+    return ms;
+  };
+  S.ms_tree = el(0, 1);
+  S.ms_grav = el(2, 3);
+  S.ms_ewald = el(4, 5);
+  S.ms_dens = el(6, 7);
+  S.ms_hmax = el(8, 9);
+  S.ms_hydro = el(10, 11);
+  *out = S;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_tree_dump(ghip_ctx *ctx, int which, int *nelem, double *xm4, double *cl4,
+                              int *lk4, double *aux, int *perm)
+{
+  if(!ctx || !nelem || which < 0 || which > 1)
+    return GHIP_EINVAL;
+  TreeDev &t = which ? ctx->st : ctx->gt;
+  if(!t.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_dump: tree not built");
+  *nelem = t.nelem;
+  if(t.n == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  size_t ne = (size_t) t.nelem;
+  if(xm4)
+    HIPCHK(hipMemcpyAsync(xm4, t.xm.p, ne * 32, hipMemcpyDeviceToHost, st));
+  if(cl4)
+    HIPCHK(hipMemcpyAsync(cl4, t.cl.p, ne * 32, hipMemcpyDeviceToHost, st));
+  if(lk4)
+    HIPCHK(hipMemcpyAsync(lk4, t.lk.p, ne * 16, hipMemcpyDeviceToHost, st));
+  if(aux)
+    HIPCHK(hipMemcpyAsync(aux, t.aux.p, ne * 8, hipMemcpyDeviceToHost, st));
+  if(perm)
+    HIPCHK(hipMemcpyAsync(perm, t.perm.p, (size_t) t.n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}

@@ -1,0 +1,160 @@
+// ghip_internal.h -- shared declarations of the gfx950 force-path library (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ghip.h"
+
+#define GHIP_BITS 21       // BITS_PER_DIMENSION, allvars.h:58
+#define GHIP_EN 64         // EN, forcetree.c:51
+#define GHIP_NTAB 1000     // NTAB, forcetree.c:28
+#define GHIP_WAVE 64
+#define GHIP_BLOCK 256
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------
+struct DevBuf
+{
+  void *p = nullptr;
+  size_t cap = 0;  // bytes
+};
+
+struct TreeDev
+{
+  int n = 0;        // particles in this tree
+  int nnodes = 0;
+  int nelem = 0;    // n + nnodes
+  // sort
+  DevBuf key, skey, idx, perm, iperm;  // u64[n], u64[n], i32[n], i32[n] (sorted->host index), i32[nhost]
+  DevBuf cpl, cnt, nb;                 // i32[n]: common prefix levels, node counts, exclusive scan
+  // pre-order element list
+  DevBuf xm, cl, lk, aux;              // double4[nelem], double4[nelem], int4[nelem], f64[nelem]
+  bool built = false;
+};
+
+struct ghip_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  int n = 0, ngas = 0;
+  // host-order fields
+  DevBuf f[GHIP_F_COUNT];
+  // staging for host<->device transfers / AoS images
+  DevBuf stage, aosP, aosS;
+  void *pinned = nullptr;
+  size_t pinned_cap = 0;
+
+  // domain
+  double corner[3] = {0, 0, 0}, center[3] = {0, 0, 0}, dlen = 0;
+  double soft[6] = {0, 0, 0, 0, 0, 0};
+
+  TreeDev gt;  // gravity tree: all particles
+  TreeDev st;  // gas tree
+  // sorted gravity-source side arrays (targets read these): x,y,z,soft,oldacc  [n]
+  DevBuf sx, sy, sz, ssoft, soldacc;
+  // gas records in gas-tree order
+  DevBuf gp;  // 8 doubles: x,y,z,m,vx,vy,vz,h
+  DevBuf gq;  // 8 doubles: pressure, density, dhsmlfac, divvel, curlvel, timestep, 0, 0
+  // density work arrays (gas-tree order)
+  DevBuf dleft, dright, drho, dnumngb, ddhsml, ddivv, drot, dflags, dtgt_a, dtgt_b;
+
+  // active lists
+  DevBuf act_host_idx;  // i32[nactive] host indices (uploaded)
+  int nactive = -1;     // -1: all
+  bool lists_dirty = true;
+  DevBuf tg_grav, tg_gas;  // sorted-order target lists
+  int nt_grav = 0, nt_gas = 0;
+  int shard_rank = 0, shard_n = 1;
+
+  // walk outputs in target order
+  DevBuf tax, tay, taz, tcost;
+
+  // ewald
+  DevBuf ewtab;   // double4[(EN+1)^3]: fx,fy,fz,0 scaled by 1/Box^2
+  double ew_box = 0;
+  DevBuf srtab;   // float[NTAB]
+  bool srtab_ready = false;
+
+  // scan/sort temp
+  DevBuf cubtmp;
+  // counters (device): 8 x u64
+  DevBuf counters;
+  ghip_stats stats;
+  hipEvent_t ev[12];
+  bool ev_ready = false;
+};
+
+int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
+
+#define HIPCHK(call)                                                                         \
+  do                                                                                         \
+    {                                                                                        \
+      hipError_t e_ = (call);                                                                \
+      if(e_ != hipSuccess)                                                                   \
+        return ghip_fail(ctx, GHIP_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,        \
+                         hipGetErrorString(e_));                                             \
+    }                                                                                        \
+  while(0)
+
+#define GCHK(call)            \
+  do                          \
+    {                         \
+      int r_ = (call);        \
+      if(r_ != GHIP_OK)       \
+        return r_;            \
+    }                         \
+  while(0)
+
+int ghip_ensure(ghip_ctx *ctx, DevBuf &b, size_t bytes);
+static inline int cdiv(long long a, int b) { return (int) ((a + b - 1) / b); }
+
+template <class T> static inline T *P(DevBuf &b) { return reinterpret_cast<T *>(b.p); }
+template <class T> static inline const T *P(const DevBuf &b) { return reinterpret_cast<const T *>(b.p); }
+
+// tree.hip
+int ghip_tree_build_impl(ghip_ctx *ctx);
+int ghip_build_target_lists(ghip_ctx *ctx);
+int ghip_gastree_refresh_hmax(ghip_ctx *ctx);
+int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst);
+// gravity.hip
+int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
+// sph.hip
+int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p);
+int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+// element link record: x = skip (element index after this subtree), y = sorted particle index
+// for a particle element or -(level+1) for a node, z = first particle of the node, w = count
+#define LK_IS_PARTICLE(lk) ((lk).y >= 0)
+
+__device__ __forceinline__ double d_nearest(double x, double boxsize, double boxhalf)
+{
+  // forcetree.c:49 NEAREST
+  return (x > boxhalf) ? (x - boxsize) : ((x < -boxhalf) ? (x + boxsize) : x);
+}
+
+__device__ __forceinline__ double d_ngb_periodic(double x, int periodic, double boxsize,
+                                                 double boxhalf)
+{
+  // allvars.h:300-308 NGB_PERIODIC_LONG_*
+  double xt = fabs(x);
+  return (periodic && xt > boxhalf) ? (boxsize - xt) : xt;
+}
+
+__device__ __forceinline__ unsigned long long d_wave_sum_u64(unsigned long long v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}

@@ -1,0 +1,787 @@
+// ghip_sph.hip -- SPH density and hydro-force neighbour sums on gfx950.
+//
+// Replaces density()/density_evaluate() (density.c:89-704, 711-1029), hydro_force()/
+// hydro_evaluate() (hydra.c:145-813, 822-1995) and the range searches they call,
+// ngb_treefind_variable()/ngb_treefind_pairs() (ngb.c:169-297, 32-160).
+//
+// The reference first collects a neighbour list per target (a pointer-chasing range search) and
+// then loops over it.  Here one wavefront serves a bucket of 64 targets that are consecutive
+// along the space-filling curve and walks the GAS tree's pre-order element list with a
+// wave-uniform index: a node is descended if ANY lane's search sphere overlaps it (the
+// reference's own node test, per lane), candidate gas records arrive as 64-byte scalar loads,
+// and each lane applies the reference's exact acceptance test (r2 < h_i^2, or r2 < h_i^2 ||
+// r2 < h_j^2 for pairs) before accumulating.  Neighbour SETS are geometric, so they are
+// identical to the reference's; only the summation order follows this tree's depth-first order.
+#include <hipcub/hipcub.hpp>
+
+#include "ghip_internal.h"
+
+// allvars.h:247-253
+#define KERNEL_COEFF_1 2.546479089470
+#define KERNEL_COEFF_2 15.278874536822
+#define KERNEL_COEFF_3 45.836623610466
+#define KERNEL_COEFF_4 30.557749073644
+#define KERNEL_COEFF_5 5.092958178941
+#define KERNEL_COEFF_6 (-15.278874536822)
+#define NORM_COEFF 4.188790204786
+#define NUMDIMS 3
+#define GAMMA (7. / 5.)  // allvars.h:64 (this fork: 7/5, not 5/3)
+#define GAMMA_MINUS1 (GAMMA - 1)
+#define FACT1 0.366025403785  // allvars.h:310
+#define LEAF_DIRECT 16        // nodes with <= this many particles are swept as a flat range
+
+struct BoxK
+{
+  double boxsize, boxhalf;
+  int periodic;
+};
+
+// node test of ngb_treefind_* (ngb.c:276-289 / 136-151): true if the node must be opened
+__device__ __forceinline__ bool d_node_overlaps(const double4 c, double dist, double px, double py,
+                                                double pz, const BoxK b)
+{
+  const double len = c.w;
+  dist += 0.5 * len;
+  double dx = d_ngb_periodic(c.x - px, b.periodic, b.boxsize, b.boxhalf);
+  if(dx > dist)
+    return false;
+  double dy = d_ngb_periodic(c.y - py, b.periodic, b.boxsize, b.boxhalf);
+  if(dy > dist)
+    return false;
+  double dz = d_ngb_periodic(c.z - pz, b.periodic, b.boxsize, b.boxhalf);
+  if(dz > dist)
+    return false;
+  dist += FACT1 * len;
+  return !(dx * dx + dy * dy + dz * dz > dist * dist);
+}
+
+__device__ __forceinline__ double d_wrap(double d, const BoxK b)
+{
+  // density.c:838-851 / hydra.c:1251-1264
+  if(b.periodic)
+    {
+      if(d > b.boxhalf)
+        d -= b.boxsize;
+      if(d < -b.boxhalf)
+        d += b.boxsize;
+    }
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// density
+// ---------------------------------------------------------------------------------------------
+struct DensAcc
+{
+  double rho, wnum, dhsml, divv, rx, ry, rz;
+  int nn;
+};
+
+__device__ __forceinline__ void d_density_pair(const double *__restrict__ gp, int j, bool valid,
+                                               double px, double py, double pz, double vx,
+                                               double vy, double vz, double h2, double hinv,
+                                               double hinv3, double hinv4, const BoxK b, DensAcc &A)
+{
+  const double *r8 = gp + (size_t) 8 * j;  // wave-uniform address: scalar loads
+  const double jx = r8[0], jy = r8[1], jz = r8[2], mass_j = r8[3];
+  const double jvx = r8[4], jvy = r8[5], jvz = r8[6];
+  double dx = d_wrap(px - jx, b), dy = d_wrap(py - jy, b), dz = d_wrap(pz - jz, b);
+  double r2 = dx * dx + dy * dy + dz * dz;
+  if(valid && r2 < h2)
+    {
+      A.nn++;
+      double r = sqrt(r2);
+      double u = r * hinv, wk, dwk;
+      if(u < 0.5)
+        {
+          wk = hinv3 * (KERNEL_COEFF_1 + KERNEL_COEFF_2 * (u - 1) * u * u);
+          dwk = hinv4 * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4);
+        }
+      else
+        {
+          wk = hinv3 * KERNEL_COEFF_5 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+          dwk = hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
+        }
+      A.rho += mass_j * wk;
+      A.wnum += NORM_COEFF * wk / hinv3;
+      A.dhsml += -mass_j * (NUMDIMS * hinv * wk + u * dwk);
+      if(r > 0)
+        {
+          double fac = mass_j * dwk / r;
+          double dvx = vx - jvx, dvy = vy - jvy, dvz = vz - jvz;
+          A.divv += -fac * (dx * dvx + dy * dvy + dz * dvz);
+          A.rx += fac * (dz * dvy - dy * dvz);
+          A.ry += fac * (dx * dvz - dz * dvx);
+          A.rz += fac * (dy * dvx - dx * dvy);
+        }
+    }
+}
+
+// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 targets per wave
+__global__ void __launch_bounds__(GHIP_BLOCK)
+k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
+          const double *__restrict__ gp, int nt, const int *__restrict__ tgt,
+          const double *__restrict__ hcur, BoxK b, double *__restrict__ orho,
+          double *__restrict__ onum, double *__restrict__ odh, double *__restrict__ odiv,
+          double *__restrict__ orot, int ngas, unsigned long long *__restrict__ counter)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
+  const int ti = wave * 64 + lane;
+  const bool valid = ti < nt;
+  const int s = valid ? tgt[ti] : 0;
+  double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, h = 1;
+  if(valid)
+    {
+      const double *r8 = gp + (size_t) 8 * s;
+      px = r8[0];
+      py = r8[1];
+      pz = r8[2];
+      vx = r8[4];
+      vy = r8[5];
+      vz = r8[6];
+      h = hcur[s];
+    }
+  const double h2 = h * h, hinv = 1.0 / h;
+  const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv;
+  DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  int e = 0;
+  while(e < nelem)
+    {
+      e = __builtin_amdgcn_readfirstlane(e);
+      const int4 k = lk[e];
+      if(LK_IS_PARTICLE(k))
+        {
+          d_density_pair(gp, k.y, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+          e = e + 1;
+        }
+      else
+        {
+          const double4 c = cl[e];
+          bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
+          if(__any(open))
+            {
+              if(k.w <= LEAF_DIRECT)
+                {
+                  for(int j = k.z; j < k.z + k.w; j++)
+                    d_density_pair(gp, j, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b,
+                                   A);
+                  e = k.x;
+                }
+              else
+                e = e + 1;
+            }
+          else
+            e = k.x;
+        }
+    }
+  if(valid)
+    {
+      orho[s] = A.rho;
+      onum[s] = A.wnum;
+      odh[s] = A.dhsml;
+      odiv[s] = A.divv;
+      orot[s] = A.rx;
+      orot[(size_t) ngas + s] = A.ry;
+      orot[2 * (size_t) ngas + s] = A.rz;
+    }
+  unsigned long long tot = d_wave_sum_u64((unsigned long long) A.nn);
+  if(lane == 0 && tot)
+    atomicAdd(counter, tot);
+}
+
+__global__ void k_dens_init(int nt, const int *__restrict__ tgt, const double *__restrict__ gp,
+                            double *__restrict__ hcur, double *__restrict__ left,
+                            double *__restrict__ right)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  int s = tgt[ti];
+  hcur[s] = gp[(size_t) 8 * s + 7];
+  left[s] = 0;   // density.c:127
+  right[s] = 0;
+}
+
+struct DensFin
+{
+  double desnumngb, maxdev, minhsml;
+  int ti_current;
+  double timebase;
+};
+
+// finalisation + smoothing-length update, density.c:434-652, one thread per evaluated target
+__global__ void k_dens_finalize(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
+                                int n, int ngas, DensFin P, const double *__restrict__ srho,
+                                const double *__restrict__ snum, const double *__restrict__ sdh,
+                                const double *__restrict__ sdiv, const double *__restrict__ srot,
+                                double *__restrict__ hcur, double *__restrict__ left,
+                                double *__restrict__ right, const double *__restrict__ entropy,
+                                const double *__restrict__ dtentropy,
+                                const int *__restrict__ timebin, const int *__restrict__ tibeg,
+                                double *__restrict__ gp, double *__restrict__ gq,
+                                double *__restrict__ o_hsml, double *__restrict__ o_numngb,
+                                double *__restrict__ o_density, double *__restrict__ o_dhf,
+                                double *__restrict__ o_divv, double *__restrict__ o_curl,
+                                double *__restrict__ o_pres, int *__restrict__ redo)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  const int s = tgt[ti];
+  const int i = perm[s];
+  double h = hcur[s];
+  double rho = srho[s], numngb = snum[s], dhf = sdh[s], divv = sdiv[s];
+  double r0 = srot[s], r1 = srot[(size_t) ngas + s], r2 = srot[2 * (size_t) ngas + s];
+  double curl = 0;
+  if(rho > 0)
+    {
+      dhf *= h / (NUMDIMS * rho);
+      if(dhf > -0.9)
+        dhf = 1 / (1 + dhf);
+      else
+        dhf = 1;
+      curl = sqrt(r0 * r0 + r1 * r1 + r2 * r2) / rho;
+      divv /= rho;
+    }
+  int tb = timebin[i];
+  int dt_step = (tb ? (1 << tb) : 0);
+  double dt_entr = (P.ti_current - (tibeg[i] + dt_step / 2)) * P.timebase;
+  double pres = (entropy[i] + dtentropy[i] * dt_entr) * pow(rho, GAMMA);
+
+  o_numngb[i] = numngb;
+  o_density[i] = rho;
+  o_dhf[i] = dhf;
+  o_divv[i] = divv;
+  o_curl[i] = curl;
+  o_pres[i] = pres;
+  double *q = gq + (size_t) 8 * s;
+  q[0] = pres;
+  q[1] = rho;
+  q[2] = dhf;
+  q[3] = divv;
+  q[4] = curl;
+
+  int again = 0;
+  double hnew = h;
+  if(numngb < (P.desnumngb - P.maxdev) ||
+     (numngb > (P.desnumngb + P.maxdev) && h > (1.01 * P.minhsml)))
+    {
+      again = 1;
+      double L = left[s], R = right[s];
+      if(L > 0 && R > 0 && (R - L) < 1.0e-3 * L)
+        again = 0;  // density.c:566-573 "this one should be ok"
+      else
+        {
+          if(numngb < (P.desnumngb - P.maxdev))
+            L = (h > L) ? h : L;
+          else
+            {
+              if(R != 0)
+                {
+                  if(h < R)
+                    R = h;
+                }
+              else
+                R = h;
+            }
+          if(R > 0 && L > 0)
+            hnew = pow(0.5 * (pow(L, 3) + pow(R, 3)), 1.0 / 3);
+          else
+            {
+              if(R == 0 && L > 0)
+                {
+                  if(fabs(numngb - P.desnumngb) < 0.5 * P.desnumngb)
+                    {
+                      double fac = 1 - (numngb - P.desnumngb) / (NUMDIMS * numngb) * dhf;
+                      hnew = (fac < 1.26) ? h * fac : h * 1.26;
+                    }
+                  else
+                    hnew = h * 1.26;
+                }
+              if(R > 0 && L == 0)
+                {
+                  if(fabs(numngb - P.desnumngb) < 0.5 * P.desnumngb)
+                    {
+                      double fac = 1 - (numngb - P.desnumngb) / (NUMDIMS * numngb) * dhf;
+                      hnew = (fac > 1 / 1.26) ? h * fac : h / 1.26;
+                    }
+                  else
+                    hnew = h / 1.26;
+                }
+            }
+          if(hnew < P.minhsml)
+            hnew = P.minhsml;
+          left[s] = L;
+          right[s] = R;
+        }
+    }
+  hcur[s] = hnew;
+  gp[(size_t) 8 * s + 7] = hnew;
+  o_hsml[i] = hnew;
+  redo[ti] = again;
+}
+
+static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
+{
+  int per = (nt + ctx->shard_n - 1) / ctx->shard_n;
+  int a = ctx->shard_rank * per;
+  int b = a + per;
+  if(a > nt)
+    a = nt;
+  if(b > nt)
+    b = nt;
+  *lo = a;
+  *cnt = b - a;
+}
+
+static int dens_alloc(ghip_ctx *ctx)
+{
+  size_t ng = (size_t) (ctx->ngas > 0 ? ctx->ngas : 1);
+  GCHK(ghip_ensure(ctx, ctx->dleft, ng * 8));
+  GCHK(ghip_ensure(ctx, ctx->dright, ng * 8));
+  GCHK(ghip_ensure(ctx, ctx->drho, ng * 8));     // doubles as hcur? no: separate below
+  GCHK(ghip_ensure(ctx, ctx->dnumngb, ng * 8));
+  GCHK(ghip_ensure(ctx, ctx->ddhsml, ng * 8 * 2));  // dhsml sums + hcur
+  GCHK(ghip_ensure(ctx, ctx->ddivv, ng * 8));
+  GCHK(ghip_ensure(ctx, ctx->drot, ng * 8 * 3));
+  GCHK(ghip_ensure(ctx, ctx->dflags, ng * 4));
+  GCHK(ghip_ensure(ctx, ctx->dtgt_a, ng * 4 + 16));
+  GCHK(ghip_ensure(ctx, ctx->dtgt_b, ng * 4 + 16));
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  return GHIP_OK;
+}
+
+int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
+{
+  if(!ctx->st.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: call ghip_tree_build first");
+  GCHK(ghip_build_target_lists(ctx));
+  ghip_stats &S = ctx->stats;
+  S.dens_neighbours = 0;
+  S.dens_target_evals = 0;
+  S.dens_iterations = 0;
+  int ng = ctx->ngas, n = ctx->n;
+  int lo, nt;
+  shard_slice(ctx, ctx->nt_gas, &lo, &nt);
+  if(ng == 0 || nt == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  TreeDev &t = ctx->st;
+  GCHK(dens_alloc(ctx));
+  double *hcur = P<double>(ctx->ddhsml) + ng;
+  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 4;
+  int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
+  HIPCHK(hipMemsetAsync(counter, 0, 8, st));
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+
+  int *cur = P<int>(ctx->dtgt_a), *nxt = P<int>(ctx->dtgt_b);
+  HIPCHK(hipMemcpyAsync(cur, P<int>(ctx->tg_gas) + lo, (size_t) nt * 4, hipMemcpyDeviceToDevice,
+                        st));
+  k_dens_init<<<cdiv(nt, 256), 256, 0, st>>>(nt, cur, P<double>(ctx->gp), hcur,
+                                             P<double>(ctx->dleft), P<double>(ctx->dright));
+  BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
+  DensFin F = {p->DesNumNgb, p->MaxNumNgbDeviation, p->MinGasHsml, p->Ti_Current,
+               p->Timebase_interval};
+  int maxiter = p->MaxIter > 0 ? p->MaxIter : 150;
+  int ncur = nt, iter = 0;
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, cur, P<int>(ctx->dflags), nxt, dnum, nt, st));
+  GCHK(ghip_ensure(ctx, ctx->cubtmp, tb + 256));
+
+  while(ncur > 0)
+    {
+      k_density<<<cdiv(ncur, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
+        t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), ncur, cur, hcur, b,
+        P<double>(ctx->drho), P<double>(ctx->dnumngb), P<double>(ctx->ddhsml),
+        P<double>(ctx->ddivv), P<double>(ctx->drot), ng, counter);
+      k_dens_finalize<<<cdiv(ncur, 256), 256, 0, st>>>(
+        ncur, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
+        P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
+        P<double>(ctx->dleft), P<double>(ctx->dright), P<double>(ctx->f[GHIP_F_ENTROPY]),
+        P<double>(ctx->f[GHIP_F_DTENTROPY]), P<int>(ctx->f[GHIP_F_TIMEBIN]),
+        P<int>(ctx->f[GHIP_F_TI_BEGSTEP]), P<double>(ctx->gp), P<double>(ctx->gq),
+        P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_NUMNGB]),
+        P<double>(ctx->f[GHIP_F_DENSITY]), P<double>(ctx->f[GHIP_F_DHSMLFAC]),
+        P<double>(ctx->f[GHIP_F_DIVVEL]), P<double>(ctx->f[GHIP_F_CURLVEL]),
+        P<double>(ctx->f[GHIP_F_PRESSURE]), P<int>(ctx->dflags));
+      HIPCHK(hipGetLastError());
+      S.dens_target_evals += ncur;
+      size_t tb2 = ctx->cubtmp.cap;
+      HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb2, cur, P<int>(ctx->dflags), nxt, dnum,
+                                           ncur, st));
+      int left = 0;
+      HIPCHK(hipMemcpyAsync(&left, dnum, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      ncur = left;
+      int *tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+      if(ncur > 0)
+        {
+          iter++;
+          if(iter > maxiter)
+            return ghip_fail(ctx, GHIP_ENOCONV,
+                             "density: %d particles not converged after %d h-iterations "
+                             "(reference: endrun(1155), density.c:669-674)", ncur, maxiter);
+        }
+    }
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  S.dens_iterations = iter;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_density(ghip_ctx *ctx, const ghip_dens_params *p)
+{
+  if(!ctx || !p)
+    return GHIP_EINVAL;
+  return ghip_density_impl(ctx, p);
+}
+
+extern "C" int ghip_update_hmax(ghip_ctx *ctx)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  if(!ctx->st.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_update_hmax: no tree");
+  return ghip_gastree_refresh_hmax(ctx);
+}
+
+extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, int target,
+                                     double h, double out7[7])
+{
+  if(!ctx || !p || !out7)
+    return GHIP_EINVAL;
+  if(!ctx->st.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_density_evaluate: no tree");
+  if(target < 0 || target >= ctx->ngas)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_density_evaluate: target %d is not a gas particle",
+                     target);
+  hipStream_t st = ctx->stream;
+  TreeDev &t = ctx->st;
+  int ng = ctx->ngas;
+  GCHK(dens_alloc(ctx));
+  double *hcur = P<double>(ctx->ddhsml) + ng;
+  int s = 0;
+  HIPCHK(hipMemcpyAsync(&s, P<int>(t.iperm) + target, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int *cur = P<int>(ctx->dtgt_a);
+  HIPCHK(hipMemcpyAsync(cur, &s, 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
+  BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
+  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
+  k_density<<<1, GHIP_BLOCK, 0, st>>>(t.nelem, P<double4>(t.cl), P<int4>(t.lk),
+                                      P<double>(ctx->gp), 1, cur, hcur, b, P<double>(ctx->drho),
+                                      P<double>(ctx->dnumngb), P<double>(ctx->ddhsml),
+                                      P<double>(ctx->ddivv), P<double>(ctx->drot), ng, counter);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&out7[0], P<double>(ctx->drho) + s, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&out7[1], P<double>(ctx->dnumngb) + s, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&out7[2], P<double>(ctx->ddhsml) + s, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&out7[3], P<double>(ctx->ddivv) + s, 8, hipMemcpyDeviceToHost, st));
+  for(int c = 0; c < 3; c++)
+    HIPCHK(hipMemcpyAsync(&out7[4 + c], P<double>(ctx->drot) + (size_t) c * ng + s, 8,
+                          hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour list for one search centre (compat surface of ngb_treefind_variable / _pairs)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_ngb_find(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
+                           const double *__restrict__ aux, const double *__restrict__ gp,
+                           const int *__restrict__ perm, double cx, double cy, double cz,
+                           double hsml, int pairs, BoxK b, int cap, int *__restrict__ list,
+                           int *__restrict__ count)
+{
+  if(threadIdx.x != 0 || blockIdx.x != 0)
+    return;
+  int num = 0;
+  int e = 0;
+  while(e < nelem)
+    {
+      const int4 k = lk[e];
+      if(LK_IS_PARTICLE(k))
+        {
+          const double *r8 = gp + (size_t) 8 * k.y;
+          double dist = hsml;
+          if(pairs && r8[7] > dist)
+            dist = r8[7];
+          e = e + 1;
+          double dx = d_ngb_periodic(r8[0] - cx, b.periodic, b.boxsize, b.boxhalf);
+          if(dx > dist)
+            continue;
+          double dy = d_ngb_periodic(r8[1] - cy, b.periodic, b.boxsize, b.boxhalf);
+          if(dy > dist)
+            continue;
+          double dz = d_ngb_periodic(r8[2] - cz, b.periodic, b.boxsize, b.boxhalf);
+          if(dz > dist)
+            continue;
+          if(dx * dx + dy * dy + dz * dz > dist * dist)
+            continue;
+          if(num < cap)
+            list[num] = perm[k.y];
+          num++;
+        }
+      else
+        {
+          double dist = hsml;
+          if(pairs && aux[e] > dist)
+            dist = aux[e];
+          e = d_node_overlaps(cl[e], dist, cx, cy, cz, b) ? e + 1 : k.x;
+        }
+    }
+  *count = num;
+}
+
+extern "C" int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double hsml, int pairs,
+                                 int periodic, double boxsize, int *ngblist, int cap, int *nfound)
+{
+  if(!ctx || !center || !nfound || cap < 0 || (cap > 0 && !ngblist))
+    return GHIP_EINVAL;
+  if(!ctx->st.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_ngb_treefind: no tree");
+  *nfound = 0;
+  TreeDev &t = ctx->st;
+  if(t.n == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) (cap + 4) * 4));
+  int *dlist = P<int>(ctx->stage) + 4, *dcount = P<int>(ctx->stage);
+  BoxK b = {boxsize, 0.5 * boxsize, periodic};
+  k_ngb_find<<<1, 64, 0, st>>>(t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux),
+                               P<double>(ctx->gp), P<int>(t.perm), center[0], center[1], center[2],
+                               hsml, pairs, b, cap, dlist, dcount);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(nfound, dcount, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int ncopy = *nfound < cap ? *nfound : cap;
+  if(ncopy > 0)
+    {
+      HIPCHK(hipMemcpyAsync(ngblist, dlist, (size_t) ncopy * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hydro
+// ---------------------------------------------------------------------------------------------
+struct HydK
+{
+  double visc_const, hubble_a2, fac_mu, fac_vsic_fix, timebase;
+  int comoving;
+};
+
+struct HydAcc
+{
+  double ax, ay, az, dtent, maxsig;
+  int np;
+};
+
+struct HydTgt
+{
+  double px, py, pz, vx, vy, vz, h_i, h_i2, mass, rho, f1, p_over_rho2_i, soundspeed_i, timestep;
+};
+
+__device__ __forceinline__ void d_hydro_pair(const double *__restrict__ gp,
+                                             const double *__restrict__ gq, int j, bool valid,
+                                             const HydTgt &T, const HydK &K, const BoxK b,
+                                             HydAcc &A)
+{
+  const double *r8 = gp + (size_t) 8 * j;  // wave-uniform: scalar loads
+  const double *q8 = gq + (size_t) 8 * j;
+  const double jx = r8[0], jy = r8[1], jz = r8[2], mass_j = r8[3];
+  const double jvx = r8[4], jvy = r8[5], jvz = r8[6], h_j = r8[7];
+  double dx = d_wrap(T.px - jx, b), dy = d_wrap(T.py - jy, b), dz = d_wrap(T.pz - jz, b);
+  double r2 = dx * dx + dy * dy + dz * dz;
+  // hydra.c:1266-1269
+  if(valid && (r2 < T.h_i2 || r2 < h_j * h_j) && r2 > 0)
+    {
+      A.np++;
+      const double pres_j = q8[0], rho_j = q8[1], dhf_j = q8[2], divv_j = q8[3], curl_j = q8[4],
+                   ts_j = q8[5];
+      double r = sqrt(r2);
+      double p_over_rho2_j = pres_j / (rho_j * rho_j);
+      double soundspeed_j = sqrt(GAMMA * p_over_rho2_j * rho_j);
+      double dvx = T.vx - jvx, dvy = T.vy - jvy, dvz = T.vz - jvz;
+      double vdotr = dx * dvx + dy * dvy + dz * dvz;
+      double vdotr2 = K.comoving ? vdotr + K.hubble_a2 * r2 : vdotr;
+      double dwk_i = 0, dwk_j = 0;
+      if(r2 < T.h_i2)
+        {
+          double hinv = 1.0 / T.h_i;
+          double hinv4 = hinv * hinv * hinv * hinv;
+          double u = r * hinv;
+          dwk_i = (u < 0.5) ? hinv4 * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4)
+                            : hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
+        }
+      if(r2 < h_j * h_j)
+        {
+          double hinv = 1.0 / h_j;
+          double hinv4 = hinv * hinv * hinv * hinv;
+          double u = r * hinv;
+          dwk_j = (u < 0.5) ? hinv4 * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4)
+                            : hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
+        }
+      double vsig = T.soundspeed_i + soundspeed_j;
+      if(vsig > A.maxsig)
+        A.maxsig = vsig;
+      double visc = 0;
+      if(vdotr2 < 0)
+        {
+          // hydra.c:1512-1594
+          double mu_ij = K.fac_mu * vdotr2 / r;
+          vsig -= 3 * mu_ij;
+          if(vsig > A.maxsig)
+            A.maxsig = vsig;
+          double rho_ij = 0.5 * (T.rho + rho_j);
+          double f2 = fabs(divv_j) / (fabs(divv_j) + curl_j + 0.0001 * soundspeed_j / K.fac_mu / h_j);
+          visc = 0.25 * K.visc_const * vsig * (-mu_ij) / rho_ij * (T.f1 + f2);
+          double tmax = (T.timestep > ts_j) ? T.timestep : ts_j;
+          double dt = 2 * tmax * K.timebase;
+          if(dt > 0 && (dwk_i + dwk_j) < 0)
+            {
+              double lim = 0.5 * K.fac_vsic_fix * vdotr2 /
+                           (0.5 * (T.mass + mass_j) * (dwk_i + dwk_j) * r * dt);
+              if(lim < visc)
+                visc = lim;
+            }
+        }
+      p_over_rho2_j *= dhf_j;
+      double hfc_visc = 0.5 * mass_j * visc * (dwk_i + dwk_j) / r;
+      double hfc = hfc_visc + mass_j * (T.p_over_rho2_i * dwk_i + p_over_rho2_j * dwk_j) / r;
+      A.ax += -hfc * dx;
+      A.ay += -hfc * dy;
+      A.az += -hfc * dz;
+      A.dtent += 0.5 * hfc_visc * vdotr2;
+    }
+}
+
+// hydro_evaluate (hydra.c:822-1995, mode 0) + the entropy-rate conversion of hydro_force
+// (hydra.c:583) for a bucket of 64 targets per wave
+__global__ void __launch_bounds__(GHIP_BLOCK)
+k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
+        const double *__restrict__ aux, const double *__restrict__ gp,
+        const double *__restrict__ gq, int nt, const int *__restrict__ tgt,
+        const int *__restrict__ perm, BoxK b, HydK K, int ngas, double *__restrict__ o_acc,
+        double *__restrict__ o_dtent, double *__restrict__ o_maxsig,
+        unsigned long long *__restrict__ counter)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
+  const int ti = wave * 64 + lane;
+  const bool valid = ti < nt;
+  const int s = valid ? tgt[ti] : 0;
+  HydTgt T = {0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 0};
+  if(valid)
+    {
+      const double *r8 = gp + (size_t) 8 * s;
+      const double *q8 = gq + (size_t) 8 * s;
+      T.px = r8[0];
+      T.py = r8[1];
+      T.pz = r8[2];
+      T.mass = r8[3];
+      T.vx = r8[4];
+      T.vy = r8[5];
+      T.vz = r8[6];
+      T.h_i = r8[7];
+      T.h_i2 = T.h_i * T.h_i;
+      double pres = q8[0];
+      T.rho = q8[1];
+      double dhf = q8[2], divv = q8[3], curl = q8[4];
+      T.timestep = q8[5];
+      // hydra.c:958-975, 1154-1156
+      T.soundspeed_i = sqrt(GAMMA * pres / T.rho);
+      T.f1 = fabs(divv) / (fabs(divv) + curl + 0.0001 * T.soundspeed_i / T.h_i / K.fac_mu);
+      T.p_over_rho2_i = pres / (T.rho * T.rho);
+      T.p_over_rho2_i *= dhf;
+    }
+  HydAcc A = {0, 0, 0, 0, 0, 0};
+
+  int e = 0;
+  while(e < nelem)
+    {
+      e = __builtin_amdgcn_readfirstlane(e);
+      const int4 k = lk[e];
+      if(LK_IS_PARTICLE(k))
+        {
+          d_hydro_pair(gp, gq, k.y, valid, T, K, b, A);
+          e = e + 1;
+        }
+      else
+        {
+          const double4 c = cl[e];
+          const double hm = aux[e];  // Extnodes[].hmax
+          double dist = (hm > T.h_i) ? hm : T.h_i;  // ngb.c:136
+          bool open = valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
+          if(__any(open))
+            {
+              if(k.w <= LEAF_DIRECT)
+                {
+                  for(int j = k.z; j < k.z + k.w; j++)
+                    d_hydro_pair(gp, gq, j, valid, T, K, b, A);
+                  e = k.x;
+                }
+              else
+                e = e + 1;
+            }
+          else
+            e = k.x;
+        }
+    }
+  if(valid)
+    {
+      const int i = perm[s];
+      o_acc[i] = A.ax;
+      o_acc[(size_t) ngas + i] = A.ay;
+      o_acc[2 * (size_t) ngas + i] = A.az;
+      // hydra.c:583
+      o_dtent[i] = A.dtent * (GAMMA_MINUS1 / (K.hubble_a2 * pow(T.rho, GAMMA_MINUS1)));
+      o_maxsig[i] = A.maxsig;
+    }
+  unsigned long long tot = d_wave_sum_u64((unsigned long long) A.np);
+  if(lane == 0 && tot)
+    atomicAdd(counter, tot);
+}
+
+int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
+{
+  if(!ctx->st.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_hydro: call ghip_tree_build first");
+  GCHK(ghip_build_target_lists(ctx));
+  ghip_stats &S = ctx->stats;
+  S.hydro_pairs = 0;
+  int ng = ctx->ngas;
+  int lo, nt;
+  shard_slice(ctx, ctx->nt_gas, &lo, &nt);
+  S.hydro_targets = nt;
+  if(ng == 0 || nt == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  TreeDev &t = ctx->st;
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 6;
+  HIPCHK(hipMemsetAsync(counter, 0, 8, st));
+  BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
+  HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
+            p->ComovingIntegrationOn};
+  HIPCHK(hipEventRecord(ctx->ev[10], st));
+  k_hydro<<<cdiv(nt, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
+    t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<double>(ctx->gp),
+    P<double>(ctx->gq), nt, P<int>(ctx->tg_gas) + lo, P<int>(t.perm), b, K, ng,
+    P<double>(ctx->f[GHIP_F_HYDROACCEL]), P<double>(ctx->f[GHIP_F_DTENTROPY]),
+    P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]), counter);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[11], st));
+  return GHIP_OK;
+}
+
+extern "C" int ghip_hydro(ghip_ctx *ctx, const ghip_hydro_params *p)
+{
+  if(!ctx || !p)
+    return GHIP_EINVAL;
+  return ghip_hydro_impl(ctx, p);
+}

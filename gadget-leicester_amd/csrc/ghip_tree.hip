@@ -1,0 +1,687 @@
+// ghip_tree.hip -- device oct-tree build for the gfx950 force path.
+//
+// Replaces force_treebuild()/force_treebuild_single()/force_update_node_recursive()
+// (forcetree.c:67-872).  The reference inserts particles one by one into an oct-tree whose cells
+// are fixed by DomainCorner/DomainLen and the Morton bits of each particle (forcetree.c:181-217)
+// and then threads it with nextnode/sibling links in depth-first order (forcetree.c:468-872).
+// Here the same cells are derived in parallel from the sorted Morton keys:
+//   * a cell at level L exists for every maximal run of >= 2 sorted keys sharing their top 3L
+//     bits -- exactly the internal nodes the reference's insertion creates (single-child chains
+//     included), minus its empty / single-particle top-level nodes, which never contribute to a
+//     force (forcetree.c:1996-2004);
+//   * the depth-first ("threaded") order is the order of the sorted keys, so the tree is stored
+//     as ONE pre-order element list (nodes and particles interleaved) in which "nextnode" is
+//     simply e+1 and "sibling" is a stored skip index.  A wavefront walks it with a wave-uniform
+//     element index, i.e. with scalar loads.
+// Children are visited in Morton-octant order (x lowest bit), the order of Nodes[].u.suns[].
+#include <hipcub/hipcub.hpp>
+
+#include "ghip_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// keys
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long d_spread3(unsigned long long v)
+{
+  // spread the low 21 bits of v so that bit b lands at bit 3b
+  v &= 0x1fffffULL;
+  v = (v | (v << 32)) & 0x001f00000000ffffULL;
+  v = (v | (v << 16)) & 0x001f0000ff0000ffULL;
+  v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+  v = (v | (v << 2)) & 0x1249249249249249ULL;
+  return v;
+}
+
+// peano.c:320-333 morton_key: x is the lowest bit of each triplet
+__device__ __forceinline__ unsigned long long d_morton21(int x, int y, int z)
+{
+  return d_spread3((unsigned long long) x) | (d_spread3((unsigned long long) y) << 1) |
+         (d_spread3((unsigned long long) z) << 2);
+}
+
+__global__ void k_morton_from_pos(int n, const double *__restrict__ x, const double *__restrict__ y,
+                                  const double *__restrict__ z, double cx, double cy, double cz,
+                                  double fac, unsigned long long *__restrict__ key,
+                                  int *__restrict__ idx)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  // forcetree.c:181-185: (int) ((Pos - DomainCorner) * DomainFac)
+  int ix = (int) ((x[i] - cx) * fac);
+  int iy = (int) ((y[i] - cy) * fac);
+  int iz = (int) ((z[i] - cz) * fac);
+  key[i] = d_morton21(ix, iy, iz);
+  idx[i] = i;
+}
+
+__global__ void k_morton_from_ints(int n, const int *__restrict__ x, const int *__restrict__ y,
+                                   const int *__restrict__ z, int bits,
+                                   unsigned long long *__restrict__ key)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  unsigned long long m = d_morton21(x[i], y[i], z[i]);
+  if(bits < 21)
+    m &= ((1ULL << (3 * bits)) - 1ULL);
+  key[i] = m;
+}
+
+// peano.c:300-316 peano_hilbert_key.  The reference drives a 48-state table; the same curve is
+// generated here from its definition: base octant order ph_base (octant = 4*xbit + 2*ybit + zbit)
+// and the cube symmetry carried by each sub-cell (signed axis permutation, out[i] =
+// in[perm[i]] ^ flip[i]).  Orientation g starts as the identity; per level:
+// local = g(octant); digit = ph_base[local]; g <- child[local] o g.
+__constant__ unsigned char c_ph_base[8] = {0, 7, 1, 6, 3, 4, 2, 5};
+__constant__ unsigned char c_ph_perm[8][3] = {{0, 2, 1}, {0, 2, 1}, {2, 1, 0}, {2, 1, 0},
+                                              {0, 1, 2}, {0, 1, 2}, {2, 1, 0}, {2, 1, 0}};
+__constant__ unsigned char c_ph_flip[8][3] = {{0, 0, 0}, {0, 1, 1}, {0, 0, 0}, {1, 0, 1},
+                                              {1, 1, 0}, {1, 1, 0}, {0, 0, 0}, {1, 0, 1}};
+
+__global__ void k_peano_from_ints(int n, const int *__restrict__ x, const int *__restrict__ y,
+                                  const int *__restrict__ z, int bits,
+                                  unsigned long long *__restrict__ key)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int v[3] = {x[i], y[i], z[i]};
+  int perm0 = 0, perm1 = 1, perm2 = 2, f0 = 0, f1 = 0, f2 = 0;
+  unsigned long long k = 0;
+  for(int b = bits - 1; b >= 0; b--)
+    {
+      int bit[3] = {(v[0] >> b) & 1, (v[1] >> b) & 1, (v[2] >> b) & 1};
+      int w0 = bit[perm0] ^ f0, w1 = bit[perm1] ^ f1, w2 = bit[perm2] ^ f2;
+      int local = w0 * 4 + w1 * 2 + w2;
+      k = (k << 3) | c_ph_base[local];
+      int p[3] = {perm0, perm1, perm2}, f[3] = {f0, f1, f2};
+      int a0 = c_ph_perm[local][0], a1 = c_ph_perm[local][1], a2 = c_ph_perm[local][2];
+      perm0 = p[a0];
+      perm1 = p[a1];
+      perm2 = p[a2];
+      f0 = f[a0] ^ c_ph_flip[local][0];
+      f1 = f[a1] ^ c_ph_flip[local][1];
+      f2 = f[a2] ^ c_ph_flip[local][2];
+    }
+  key[i] = k;
+}
+
+extern "C" int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const int *y,
+                                       const int *z, int bits, unsigned long long *keys)
+{
+  if(!ctx || n < 0 || bits < 1 || bits > 21)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_peano_hilbert_keys: bad arguments");
+  if(n == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 3 * sizeof(int) + 8 + (size_t) n * 8));
+  int *dx = P<int>(ctx->stage), *dy = dx + n, *dz = dy + n;
+  unsigned long long *dk = reinterpret_cast<unsigned long long *>(
+    reinterpret_cast<char *>(ctx->stage.p) + (((size_t) 3 * n * sizeof(int) + 7) & ~(size_t) 7));
+  HIPCHK(hipMemcpyAsync(dx, x, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dy, y, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dz, z, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  k_peano_from_ints<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, dx, dy, dz, bits, dk);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(keys, dk, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GHIP_OK;
+}
+
+extern "C" int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y, const int *z,
+                                int bits, unsigned long long *keys)
+{
+  if(!ctx || n < 0 || bits < 1 || bits > 21)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_morton_keys: bad arguments");
+  if(n == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 3 * sizeof(int) + 8 + (size_t) n * 8));
+  int *dx = P<int>(ctx->stage), *dy = dx + n, *dz = dy + n;
+  unsigned long long *dk = reinterpret_cast<unsigned long long *>(
+    reinterpret_cast<char *>(ctx->stage.p) + (((size_t) 3 * n * sizeof(int) + 7) & ~(size_t) 7));
+  HIPCHK(hipMemcpyAsync(dx, x, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dy, y, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dz, z, (size_t) n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  k_morton_from_ints<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, dx, dy, dz, bits, dk);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(keys, dk, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// structure from sorted keys
+// ---------------------------------------------------------------------------------------------
+__global__ void k_inverse_perm(int n, const int *__restrict__ perm, int *__restrict__ iperm)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    iperm[perm[s]] = s;
+}
+
+// number of leading 3-bit digits two 63-bit keys share
+__device__ __forceinline__ int d_common_levels(unsigned long long a, unsigned long long b)
+{
+  unsigned long long x = a ^ b;
+  if(x == 0)
+    return GHIP_BITS;
+  return (__clzll((long long) x) - 1) / 3;
+}
+
+__global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ skey,
+                                int *__restrict__ cpl)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  cpl[i] = (i + 1 < n) ? d_common_levels(skey[i], skey[i + 1]) : -1;
+}
+
+__global__ void k_node_counts(int n, const int *__restrict__ cpl, int *__restrict__ cnt)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int cprev = (i > 0) ? cpl[i - 1] : -1;
+  int d = cpl[i] - cprev;
+  cnt[i] = d > 0 ? d : 0;
+}
+
+// one thread per particle: emits the nodes that START at this particle (levels cprev+1..c_i, in
+// increasing depth = pre-order) followed by the particle itself.
+__global__ void k_emit_elements(int n, int nelem, const unsigned long long *__restrict__ skey,
+                                const int *__restrict__ cpl, const int *__restrict__ cnt,
+                                const int *__restrict__ nb, const double *__restrict__ px,
+                                const double *__restrict__ py, const double *__restrict__ pz,
+                                const double *__restrict__ pm, const double *__restrict__ paux,
+                                double ccx, double ccy, double ccz, double dlen,
+                                double4 *__restrict__ xm, double4 *__restrict__ cl,
+                                int4 *__restrict__ lk, double *__restrict__ aux)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int cprev = (i > 0) ? cpl[i - 1] : -1;
+  int ci = cpl[i];
+  int base = i + nb[i];
+  unsigned long long ki = skey[i];
+
+  if(ci > cprev)
+    {
+      // geometry of the level-(cprev+1) cell by the reference's recurrence (forcetree.c:263-279):
+      // len halves, centre moves by a quarter of the parent's len per level
+      double len = dlen, cx = ccx, cy = ccy, cz = ccz;
+      for(int l = 1; l <= cprev + 1; l++)
+        {
+          int digit = (int) ((ki >> (63 - 3 * l)) & 7);
+          double lenhalf = 0.25 * len;
+          cx = (digit & 1) ? cx + lenhalf : cx - lenhalf;
+          cy = (digit & 2) ? cy + lenhalf : cy - lenhalf;
+          cz = (digit & 4) ? cz + lenhalf : cz - lenhalf;
+          len = 0.5 * len;
+        }
+      for(int L = cprev + 1; L <= ci; L++)
+        {
+          int e = base + (L - cprev - 1);
+          int sh = 63 - 3 * L;
+          unsigned long long prefix = ki >> sh;
+          int lo = i + 1, hi = n;
+          while(lo < hi)
+            {
+              int mid = (lo + hi) >> 1;
+              if((skey[mid] >> sh) == prefix)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+          int end = lo;
+          int skip = (end >= n) ? nelem : end + nb[end];
+          lk[e] = make_int4(skip, -(L + 1), i, end - i);
+          cl[e] = make_double4(cx, cy, cz, len);
+          xm[e] = make_double4(0, 0, 0, 0);
+          aux[e] = 0;
+          if(L < ci)
+            {
+              int digit = (int) ((ki >> (63 - 3 * (L + 1))) & 7);
+              double lenhalf = 0.25 * len;
+              cx = (digit & 1) ? cx + lenhalf : cx - lenhalf;
+              cy = (digit & 2) ? cy + lenhalf : cy - lenhalf;
+              cz = (digit & 4) ? cz + lenhalf : cz - lenhalf;
+              len = 0.5 * len;
+            }
+        }
+    }
+  int pe = base + cnt[i];
+  double x = px[i], y = py[i], z = pz[i];
+  lk[pe] = make_int4(pe + 1, i, i, 1);
+  xm[pe] = make_double4(x, y, z, pm[i]);
+  cl[pe] = make_double4(x, y, z, 0.0);
+  aux[pe] = paux[i];
+}
+
+// multipole pass of one level (force_update_node_recursive, forcetree.c:468-872): children are
+// the elements reached from e+1 by following skip links until the node's own skip.
+// GRAV: aux = largest ForceSoftening below, negated when the node mixes softenings
+//       (BITFLAG_MAX_SOFTENING_TYPE / BITFLAG_MIXED_SOFTENINGS_IN_NODE, forcetree.c:612-700)
+// GAS : aux = hmax (Extnodes[].hmax, forcetree.c:593, 676)
+template <bool GRAV, bool MOMENTS>
+__global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
+                             const double4 *__restrict__ cl, const int4 *__restrict__ lk,
+                             double *__restrict__ aux)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y != -(level + 1))
+    return;
+  double mass = 0, sx = 0, sy = 0, sz = 0;
+  double amax = 0;
+  bool aset = false, mixed = false;
+  for(int c = e + 1; c < me.x;)
+    {
+      int4 ck = lk[c];
+      if(MOMENTS)
+        {
+          double4 v = xm[c];
+          mass += v.w;
+          sx += v.w * v.x;
+          sy += v.w * v.y;
+          sz += v.w * v.z;
+        }
+      double a = aux[c];
+      if(GRAV)
+        {
+          bool cmixed = a < 0;
+          a = fabs(a);
+          mixed |= cmixed;
+          if(!aset)
+            {
+              amax = a;
+              aset = true;
+            }
+          else if(a > amax)
+            {
+              amax = a;
+              mixed = true;
+            }
+          else if(a < amax)
+            mixed = true;
+        }
+      else
+        {
+          if(a > amax)
+            amax = a;
+        }
+      c = ck.x;
+    }
+  if(MOMENTS)
+    {
+      double4 c4 = cl[e];
+      if(mass != 0)
+        {
+          sx /= mass;
+          sy /= mass;
+          sz /= mass;
+        }
+      else
+        {
+          sx = c4.x;
+          sy = c4.y;
+          sz = c4.z;
+        }
+      xm[e] = make_double4(sx, sy, sz, mass);
+    }
+  aux[e] = (GRAV && mixed) ? -amax : amax;
+}
+
+__global__ void k_set_particle_aux(int nelem, const int4 *__restrict__ lk,
+                                   const double *__restrict__ paux, double *__restrict__ aux)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y >= 0)
+    aux[e] = paux[me.y];
+}
+
+// ---------------------------------------------------------------------------------------------
+// gathers into tree order
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather_grav(int n, const int *__restrict__ perm, const double *__restrict__ x,
+                              const double *__restrict__ y, const double *__restrict__ z,
+                              const double *__restrict__ m, const int *__restrict__ type,
+                              double s0, double s1, double s2, double s3, double s4, double s5,
+                              double *__restrict__ sx, double *__restrict__ sy,
+                              double *__restrict__ sz, double *__restrict__ sm,
+                              double *__restrict__ ssoft)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  int i = perm[s];
+  sx[s] = x[i];
+  sy[s] = y[i];
+  sz[s] = z[i];
+  sm[s] = m[i];
+  int t = type[i];
+  double sf = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+  ssoft[s] = sf;
+}
+
+__global__ void k_gather_f64(int n, const int *__restrict__ perm, const double *__restrict__ src,
+                             double *__restrict__ dst)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    dst[s] = src[perm[s]];
+}
+
+// gas records in gas-tree order: gp = x,y,z,m,vx,vy,vz,h ; gq = P,rho,f,divv,curl,timestep,0,0
+__global__ void k_gather_gas(int ng, const int *__restrict__ perm, const double *__restrict__ x,
+                             const double *__restrict__ y, const double *__restrict__ z,
+                             const double *__restrict__ m, const double *__restrict__ vx,
+                             const double *__restrict__ vy, const double *__restrict__ vz,
+                             const double *__restrict__ h, const double *__restrict__ pres,
+                             const double *__restrict__ rho, const double *__restrict__ dhf,
+                             const double *__restrict__ divv, const double *__restrict__ curl,
+                             const int *__restrict__ timebin, double *__restrict__ gp,
+                             double *__restrict__ gq)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= ng)
+    return;
+  int i = perm[s];
+  double *r = gp + (size_t) 8 * s;
+  r[0] = x[i];
+  r[1] = y[i];
+  r[2] = z[i];
+  r[3] = m[i];
+  r[4] = vx[i];
+  r[5] = vy[i];
+  r[6] = vz[i];
+  r[7] = h[i];
+  double *q = gq + (size_t) 8 * s;
+  int tb = timebin[i];
+  q[0] = pres[i];
+  q[1] = rho[i];
+  q[2] = dhf[i];
+  q[3] = divv[i];
+  q[4] = curl[i];
+  q[5] = (double) (tb ? (1 << tb) : 0);  // hydra.c:966 timestep
+  q[6] = 0;
+  q[7] = 0;
+}
+
+int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst)
+{
+  if(n <= 0)
+    return GHIP_OK;
+  k_gather_f64<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, perm, src, dst);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+__global__ void k_iota(int n, int *__restrict__ a)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    a[i] = i;
+}
+
+__global__ void k_mark_active(int nact, const int *__restrict__ act, const int *__restrict__ iperm,
+                              int limit, int *__restrict__ flags)
+{
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if(a >= nact)
+    return;
+  int i = act[a];
+  if(i >= 0 && i < limit)
+    flags[iperm[i]] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------------------------
+static int cub_tmp(ghip_ctx *ctx, size_t bytes)
+{
+  return ghip_ensure(ctx, ctx->cubtmp, bytes + 256);
+}
+
+static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
+                     const double *z, const double *m, const double *aux_host_order, bool grav)
+{
+  t.n = n;
+  t.nnodes = 0;
+  t.nelem = n;
+  t.built = false;
+  if(n == 0)
+    {
+      t.built = true;
+      return GHIP_OK;
+    }
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, t.key, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, t.skey, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, t.idx, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.perm, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.cpl, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.cnt, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.nb, (size_t) (n + 1) * 4));
+
+  double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);  // DomainFac, domain.c:2012
+  k_morton_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, x, y, z, ctx->corner[0], ctx->corner[1],
+                                                  ctx->corner[2], fac,
+                                                  P<unsigned long long>(t.key), P<int>(t.idx));
+  HIPCHK(hipGetLastError());
+
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, P<unsigned long long>(t.key),
+                                            P<unsigned long long>(t.skey), P<int>(t.idx),
+                                            P<int>(t.perm), n, 0, 63, st));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, P<unsigned long long>(t.key),
+                                            P<unsigned long long>(t.skey), P<int>(t.idx),
+                                            P<int>(t.perm), n, 0, 63, st));
+
+  k_prefix_levels<<<cdiv(n, 256), 256, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl));
+  k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), P<int>(t.cnt));
+  HIPCHK(hipGetLastError());
+  tb = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
+  int last_nb = 0, last_cnt = 0;
+  HIPCHK(hipMemcpyAsync(&last_nb, P<int>(t.nb) + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&last_cnt, P<int>(t.cnt) + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  t.nnodes = last_nb + last_cnt;
+  t.nelem = n + t.nnodes;
+
+  GCHK(ghip_ensure(ctx, t.xm, (size_t) t.nelem * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, t.cl, (size_t) t.nelem * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, t.lk, (size_t) t.nelem * sizeof(int4)));
+  GCHK(ghip_ensure(ctx, t.aux, (size_t) t.nelem * sizeof(double)));
+
+  // sorted particle data into the staging buffer: x,y,z,m,aux
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 5 * sizeof(double)));
+  double *sx = P<double>(ctx->stage), *sy = sx + n, *sz = sy + n, *sm = sz + n, *sa = sm + n;
+  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), x, sx);
+  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), y, sy);
+  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), z, sz);
+  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), m, sm);
+  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), aux_host_order, sa);
+  HIPCHK(hipGetLastError());
+
+  k_emit_elements<<<cdiv(n, 256), 256, 0, st>>>(
+    n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), sx, sy,
+    sz, sm, sa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
+    P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+  HIPCHK(hipGetLastError());
+
+  for(int L = GHIP_BITS; L >= 0; L--)
+    {
+      if(grav)
+        k_node_level<true, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+      else
+        k_node_level<false, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+    }
+  HIPCHK(hipGetLastError());
+  t.built = true;
+  return GHIP_OK;
+}
+
+__global__ void k_soft_of_type(int n, const int *__restrict__ type, double s0, double s1, double s2,
+                               double s3, double s4, double s5, double *__restrict__ out)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int t = type[i];
+  out[i] = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+}
+
+int ghip_tree_build_impl(ghip_ctx *ctx)
+{
+  int n = ctx->n, ng = ctx->ngas;
+  hipStream_t st = ctx->stream;
+  const double *x = P<double>(ctx->f[GHIP_F_POS]);
+  const double *y = x + n, *z = y + n;
+  const double *m = P<double>(ctx->f[GHIP_F_MASS]);
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+  // per-particle softening in host order (aux of the gravity tree's particle elements)
+  GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) (n > 0 ? n : 1) * 8));
+  GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) (n > 0 ? n : 1) * 8));
+  double *tmp_soft = P<double>(ctx->soldacc);  // scratch until the first gravity call
+  if(n > 0)
+    k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
+                                                 ctx->soft[1], ctx->soft[2], ctx->soft[3],
+                                                 ctx->soft[4], ctx->soft[5], tmp_soft);
+  GCHK(build_one(ctx, ctx->gt, n, x, y, z, m, tmp_soft, true));
+  if(n > 0)
+    {
+      GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
+      k_inverse_perm<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->gt.perm), P<int>(ctx->gt.iperm));
+      GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
+      GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
+      GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
+      // the staging buffer still holds sorted x,y,z,m,soft from build_one
+      double *sx = P<double>(ctx->stage);
+      HIPCHK(hipMemcpyAsync(ctx->sx.p, sx, (size_t) n * 8, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->sy.p, sx + n, (size_t) n * 8, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->sz.p, sx + 2 * (size_t) n, (size_t) n * 8,
+                            hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->ssoft.p, sx + 4 * (size_t) n, (size_t) n * 8,
+                            hipMemcpyDeviceToDevice, st));
+    }
+
+  // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml
+  const double *h = P<double>(ctx->f[GHIP_F_HSML]);
+  GCHK(build_one(ctx, ctx->st, ng, x, y, z, m, h, false));
+  if(ng > 0)
+    {
+      GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
+      k_inverse_perm<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(ctx->st.perm),
+                                                    P<int>(ctx->st.iperm));
+      GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
+      GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
+      const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
+      k_gather_gas<<<cdiv(ng, 256), 256, 0, st>>>(
+        ng, P<int>(ctx->st.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
+        P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
+        P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
+        P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
+        P<double>(ctx->gq));
+    }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  ctx->stats.tree_nodes = ctx->gt.nnodes;
+  ctx->stats.gastree_nodes = ctx->st.nnodes;
+  ctx->lists_dirty = true;
+  return GHIP_OK;
+}
+
+// refresh Extnodes[].hmax of the gas tree from the current smoothing lengths in gp[].h
+// (force_update_hmax, forcetree.c:1661-1786; recomputed exactly instead of only raised)
+__global__ void k_aux_from_gp(int nelem, const int4 *__restrict__ lk,
+                              const double *__restrict__ gp, double *__restrict__ aux)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y >= 0)
+    aux[e] = gp[(size_t) 8 * me.y + 7];
+}
+
+int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
+{
+  TreeDev &t = ctx->st;
+  if(t.n == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipEventRecord(ctx->ev[8], st));
+  k_aux_from_gp<<<cdiv(t.nelem, 256), 256, 0, st>>>(t.nelem, P<int4>(t.lk), P<double>(ctx->gp),
+                                                   P<double>(t.aux));
+  for(int L = GHIP_BITS; L >= 0; L--)
+    k_node_level<false, false><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+      t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[9], st));
+  return GHIP_OK;
+}
+
+// target lists: tree-order positions of the active particles, ascending (so that 64
+// consecutive targets are spatial neighbours), sliced for this rank's shard
+static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, int *count)
+{
+  hipStream_t st = ctx->stream;
+  int n = t.n;
+  *count = 0;
+  if(n == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, list, (size_t) n * 4));
+  if(ctx->nactive < 0)
+    {
+      k_iota<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(list));
+      HIPCHK(hipGetLastError());
+      *count = n;
+      return GHIP_OK;
+    }
+  if(ctx->nactive == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, ctx->dtgt_a, (size_t) n * 4 + 16));
+  HIPCHK(hipMemsetAsync(ctx->dflags.p, 0, (size_t) n * 4, st));
+  k_mark_active<<<cdiv(ctx->nactive, 256), 256, 0, st>>>(ctx->nactive, P<int>(ctx->act_host_idx),
+                                                          P<int>(t.iperm), host_limit,
+                                                          P<int>(ctx->dflags));
+  k_iota<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->dtgt_a));
+  HIPCHK(hipGetLastError());
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, P<int>(ctx->dtgt_a), P<int>(ctx->dflags),
+                                       P<int>(list), dnum, n, st));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb, P<int>(ctx->dtgt_a),
+                                       P<int>(ctx->dflags), P<int>(list), dnum, n, st));
+  HIPCHK(hipMemcpyAsync(count, dnum, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
+int ghip_build_target_lists(ghip_ctx *ctx)
+{
+  if(!ctx->lists_dirty)
+    return GHIP_OK;
+  GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
+  GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
+  ctx->lists_dirty = false;
+  return GHIP_OK;
+}

@@ -1,0 +1,225 @@
+/*
+ * ghip.h -- C-ABI of libghip.so: the MI355X (gfx950) force path of GADGET-3 (Leicester fork).
+ *
+ * Plain C, no C++/torch types.  One ghip_ctx per process / GPU / MPI rank (the reference is
+ * single-threaded per rank, SURVEY.md 8b "Threading").  Every entry point returns 0 on success
+ * or a negative GHIP_E* code and never calls exit(); the host glue maps a failure to the
+ * reference's endrun(code) convention (endrun.c:23-38) -- see INTEGRATION.md.
+ *
+ * What each group replaces in the reference:
+ *   ghip_upload_aos / ghip_download_aos   the lazy reads/writes of P[] / SphP[] inside the walks
+ *                                         (allvars.h:1131-1377, 1384-1639)
+ *   ghip_tree_build                       force_treebuild()            forcetree.c:67-872
+ *   ghip_gravity                          the active-list loop over force_treeevaluate*()
+ *                                         gravtree.c:130-168 + forcetree.c:1797, 2330, 2873
+ *   ghip_ewald_init                       ewald_init()                 forcetree.c:4402-4527
+ *   ghip_density                          density() incl. h iteration  density.c:89-704, 711-1029
+ *   ghip_update_hmax                      force_update_hmax()          forcetree.c:1661-1786
+ *   ghip_hydro                            hydro_force()                hydra.c:145-813, 822-1995
+ *   ghip_peano_hilbert_keys               peano_hilbert_key()          peano.c:300-316
+ * The host-side mirror with the reference's own names (gravity_tree(), density(), hydro_force(),
+ * force_treeevaluate(), ...) is include/gadget_force.h.
+ */
+#ifndef GHIP_H
+#define GHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ghip_ctx ghip_ctx;
+
+/* error codes */
+#define GHIP_OK 0
+#define GHIP_EHIP (-90001)       /* a HIP runtime call failed (message in ghip_last_error) */
+#define GHIP_EINVAL (-90002)     /* bad argument / call order */
+#define GHIP_ENOMEM (-90003)     /* device or host allocation failed */
+#define GHIP_ENOCONV (-90004)    /* density h-iteration did not converge (reference: endrun(1155)) */
+#define GHIP_ENODEVICE (-90005)  /* no usable gfx950 device */
+
+/* particle fields held on the device in the host's particle order.  3-vectors are [n][3]
+ * doubles on the host side; ints are 32-bit. */
+enum ghip_field
+{
+  GHIP_F_POS = 0,        /* P[].Pos           [n][3] f64 in  */
+  GHIP_F_VEL,            /* P[].Vel           [n][3] f64 in  (node vs/vmax only) */
+  GHIP_F_MASS,           /* P[].Mass          [n]    f64 in  */
+  GHIP_F_TYPE,           /* P[].Type          [n]    i32 in  */
+  GHIP_F_OLDACC,         /* P[].OldAcc        [n]    f64 in/out */
+  GHIP_F_HSML,           /* PPP[].Hsml        [n]    f64 in/out (gas entries used) */
+  GHIP_F_TIMEBIN,        /* P[].TimeBin       [n]    i32 in  */
+  GHIP_F_TI_BEGSTEP,     /* P[].Ti_begstep    [n]    i32 in  */
+  GHIP_F_VELPRED,        /* SphP[].VelPred    [ngas][3] f64 in */
+  GHIP_F_ENTROPY,        /* SphP[].Entropy    [ngas] f64 in  */
+  GHIP_F_DTENTROPY,      /* SphP[].e.DtEntropy [ngas] f64 in (pressure prediction) / out (hydro) */
+  GHIP_F_GRAVACCEL,      /* P[].g.GravAccel   [n][3] f64 out */
+  GHIP_F_GRAVCOST,       /* P[].GravCost      [n]    i32 out (ninteractions) */
+  GHIP_F_NUMNGB,         /* PPP[].n.NumNgb    [ngas] f64 out */
+  GHIP_F_DENSITY,        /* SphP[].d.Density  [ngas] f64 in/out */
+  GHIP_F_DHSMLFAC,       /* SphP[].h.DhsmlDensityFactor [ngas] f64 in/out */
+  GHIP_F_DIVVEL,         /* SphP[].v.DivVel   [ngas] f64 in/out */
+  GHIP_F_CURLVEL,        /* SphP[].r.CurlVel  [ngas] f64 in/out */
+  GHIP_F_PRESSURE,       /* SphP[].Pressure   [ngas] f64 in/out */
+  GHIP_F_HYDROACCEL,     /* SphP[].a.HydroAccel [ngas][3] f64 out */
+  GHIP_F_MAXSIGNALVEL,   /* SphP[].MaxSignalVel [ngas] f64 out */
+  GHIP_F_COUNT
+};
+
+/* Byte layout of the host's AoS records (struct particle_data / sph_particle_data are
+ * compile-flag dependent, allvars.h:1131-1639; offsets come from a probe TU).
+ * An offset of -1 means "field absent".  Hsml/NumNgb live in P when BLACK_HOLES||DUST, else in
+ * SphP (the PPP macro, allvars.h:266-270): set exactly one of the two pairs. */
+typedef struct
+{
+  int p_stride, p_pos, p_vel, p_mass, p_gravaccel, p_oldacc, p_gravcost /* f32 */;
+  int p_ti_begstep /* i32 */, p_type /* i16 */, p_timebin /* i16 */;
+  int p_hsml, p_numngb; /* when PPP == P, else -1 */
+  int s_stride, s_entropy, s_pressure, s_velpred, s_maxsignalvel, s_density, s_dtentropy;
+  int s_hydroaccel, s_dhsmlfac, s_divvel, s_curlvel;
+  int s_hsml, s_numngb; /* when PPP == SphP, else -1 */
+} ghip_layout;
+
+typedef struct
+{
+  double ErrTolTheta;        /* All.ErrTolTheta: != 0 Barnes-Hut, == 0 relative criterion */
+  double ErrTolForceAcc;     /* All.ErrTolForceAcc */
+  double ForceSoftening[6];  /* All.ForceSoftening[] = 2.8 * SofteningTable[] (gravtree.c:881) */
+  double BoxSize;            /* All.BoxSize */
+  int periodic;              /* built with PERIODIC */
+  int unequal_softenings;    /* built with UNEQUALSOFTENINGS */
+  double Rcut, Asmth;        /* All.Rcut[0], All.Asmth[0] (PMGRID short-range walk only) */
+} ghip_grav_params;
+
+#define GHIP_WALK_NEWTON 0      /* force_treeevaluate                   forcetree.c:1797 */
+#define GHIP_WALK_SHORTRANGE 1  /* force_treeevaluate_shortrange        forcetree.c:2330 */
+#define GHIP_WALK_EWALD 2       /* force_treeevaluate_ewald_correction  forcetree.c:2873 (adds) */
+
+typedef struct
+{
+  double DesNumNgb, MaxNumNgbDeviation, MinGasHsml;  /* All.* (density.c:559-646) */
+  double BoxSize;
+  int periodic;
+  int Ti_Current;            /* All.Ti_Current */
+  double Timebase_interval;  /* All.Timebase_interval */
+  int MaxIter;               /* MAXITER (150) */
+} ghip_dens_params;
+
+typedef struct
+{
+  double ArtBulkViscConst;   /* All.ArtBulkViscConst */
+  double BoxSize;
+  int periodic;
+  int ComovingIntegrationOn;
+  double hubble_a2, fac_mu, fac_vsic_fix; /* hydra.c:192-208 (1 when not comoving) */
+  double Timebase_interval;
+} ghip_hydro_params;
+
+/* work counters of the last phase, counted exactly as the reference counts them
+ * (SURVEY.md 8d): used for roofline.achieved */
+typedef struct
+{
+  long long grav_interactions;   /* sum of ninteractions over targets (forcetree.c:2214) */
+  long long grav_targets;
+  long long ewald_interactions;  /* sum of cost (forcetree.c:3170) */
+  long long dens_neighbours;     /* neighbours with r2 < h2, summed over h-iterations (density.c:856) */
+  long long dens_target_evals;   /* target evaluations summed over h-iterations */
+  int dens_iterations;
+  long long hydro_pairs;         /* pairs passing hydra.c:1266-1269 with r > 0 */
+  long long hydro_targets;
+  int tree_nodes, gastree_nodes;
+  /* device time of the last call of each phase, ms, measured with hipEvents on the ctx stream */
+  float ms_tree, ms_grav, ms_ewald, ms_dens, ms_hmax, ms_hydro;
+} ghip_stats;
+
+/* ---- lifetime ---- */
+int ghip_create(int device, ghip_ctx **out);
+void ghip_destroy(ghip_ctx *ctx);
+const char *ghip_last_error(const ghip_ctx *ctx);
+const char *ghip_version(void);
+
+/* ---- particle data ---- */
+/* declare particle counts (gas = indices [0,ngas), allvars.h:1384); (re)allocates device arrays */
+int ghip_set_counts(ghip_ctx *ctx, int numpart, int ngas);
+/* copy one field host->device / device->host, host arrays in the plain layouts listed above */
+int ghip_set_field(ghip_ctx *ctx, int field, const void *host);
+int ghip_get_field(ghip_ctx *ctx, int field, void *host);
+/* whole-record path: H2D of the raw P[]/SphP[] blocks + device-side unpack, and the reverse
+ * (results are packed into the device image of the records, then one D2H per block) */
+int ghip_upload_aos(ghip_ctx *ctx, const void *P, const void *SphP, const ghip_layout *lay,
+                    int numpart, int ngas);
+int ghip_download_aos(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay,
+                      int want_gravity, int want_density, int want_hydro);
+
+/* ---- active list (FirstActiveParticle/NextActiveParticle, run.c:300-320) ---- */
+/* host indices of the active particles; NULL or n == numpart with idx NULL: all active */
+int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive);
+/* restrict evaluation to shard `rank` of `nranks` equal-count slices of the space-filling-curve
+ * ordered active list (multi-GPU data parallelism; results of other slices are left untouched) */
+int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks);
+
+/* shard exchange (multi-GPU; replaces the MPI export rounds gravtree.c:175-339,
+ * density.c:193-389, hydra.c:274-526).  group 0 = gravity (width 4), 1 = density (width 7),
+ * 2 = hydro (width 5).  ghip_shard_count: padded slice length `per` and this rank's count.
+ * ghip_shard_pack writes this rank's finished results as [width][per] doubles into DEVICE memory;
+ * the caller all-gathers the equal-sized blocks (RCCL) into [nranks][width][per];
+ * ghip_shard_unpack fills in the other ranks' slices. */
+int ghip_shard_count(ghip_ctx *ctx, int gas, int *per, int *mine);
+int ghip_shard_pack(ghip_ctx *ctx, int group, void *dev_buf);
+int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_all, int nranks);
+
+/* ---- the path ---- */
+int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
+                    double DomainLen, const double ForceSoftening[6]);
+int ghip_ewald_init(ghip_ctx *ctx, double BoxSize);
+/* host copy of the ewald table [3][65][65][65] already scaled by 1/BoxSize^2 */
+int ghip_ewald_get_table(ghip_ctx *ctx, double *host);
+/* walk kind: GHIP_WALK_*.  Results: GRAVACCEL (G-less, as gravtree.c:381-393 expects) and
+ * GRAVCOST of the active particles.  The EWALD walk adds to both. */
+int ghip_gravity(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
+/* external targets (the mode==1 gravdata_in record, allvars.h:1690-1703): coordinates, type,
+ * OldAcc in; Acc[3], Ninteractions out; all host arrays */
+int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
+                     const double *pos, const int *type, const double *oldacc, double *acc,
+                     int *ninteractions);
+/* OldAcc = |GravAccel| and GravAccel *= G for the active particles (gravtree.c:381-403) */
+int ghip_gravity_finish(ghip_ctx *ctx, double G);
+/* softened direct summation over all particles for the active targets (accuracy oracle on
+ * device, formula of forcetree.c:4273-4336); writes GRAVACCEL */
+int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p);
+int ghip_density(ghip_ctx *ctx, const ghip_dens_params *p);
+int ghip_update_hmax(ghip_ctx *ctx);
+int ghip_hydro(ghip_ctx *ctx, const ghip_hydro_params *p);
+
+/* one fixed-h evaluation for a single target (density_evaluate mode 0, density.c:711):
+ * out7 = rho, numngb, dhsmlrho, divv, rot[3] (raw sums, before finalisation) */
+int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, int target, double h,
+                          double out7[7]);
+/* neighbour lists for one search centre (ngb_treefind_variable / _pairs, ngb.c:169, 32):
+ * writes up to cap host indices, returns the count in *nfound */
+int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double hsml, int pairs,
+                      int periodic, double boxsize, int *ngblist, int cap, int *nfound);
+
+/* ---- keys (peano.c:300-358), device evaluation of n integer triplets ---- */
+int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const int *y, const int *z,
+                            int bits, unsigned long long *keys);
+int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y, const int *z, int bits,
+                     unsigned long long *keys);
+
+/* ---- introspection ---- */
+int ghip_get_stats(const ghip_ctx *ctx, ghip_stats *out);
+/* tree dump for parity tests: the pre-order element list of the gravity tree (which = 0) or the
+ * gas tree (which = 1): xm4 = (x,y,z,mass), cl4 = (centre, len), lk4 = (skip, particle index in
+ * tree order or -(level+1), first particle, count), aux, and perm = tree order -> host index.
+ * Pass NULL arrays to query *nelem only. */
+int ghip_tree_dump(ghip_ctx *ctx, int which, int *nelem, double *xm4, double *cl4, int *lk4,
+                   double *aux, int *perm);
+/* device stream (hipStream_t) the kernels run on, for callers that time with HIP events */
+void *ghip_stream(ghip_ctx *ctx);
+int ghip_sync(ghip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

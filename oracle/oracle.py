@@ -1,0 +1,307 @@
+"""ctypes front-end of the CPU oracle (oracle/gadget_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  PARITY UNPINNED BY UPSTREAM (see
+gadget_oracle.h): the reference has no fixtures for this path and is unbuildable here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EN = 64
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class GravParams(C.Structure):
+    _fields_ = [("ErrTolTheta", C.c_double), ("ErrTolForceAcc", C.c_double),
+                ("BoxSize", C.c_double), ("periodic", C.c_int),
+                ("unequal_softenings", C.c_int), ("rcut", C.c_double), ("asmth", C.c_double)]
+
+
+class DensParams(C.Structure):
+    _fields_ = [("DesNumNgb", C.c_double), ("MaxNumNgbDeviation", C.c_double),
+                ("MinGasHsml", C.c_double), ("BoxSize", C.c_double), ("periodic", C.c_int),
+                ("Ti_Current", C.c_int), ("Timebase_interval", C.c_double), ("maxiter", C.c_int)]
+
+
+class HydroParams(C.Structure):
+    _fields_ = [("ArtBulkViscConst", C.c_double), ("BoxSize", C.c_double), ("periodic", C.c_int),
+                ("ComovingIntegrationOn", C.c_int), ("hubble_a2", C.c_double),
+                ("fac_mu", C.c_double), ("fac_vsic_fix", C.c_double),
+                ("Timebase_interval", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libgadget_oracle.so")
+    src = os.path.join(_HERE, "gadget_oracle.c")
+    hdr = os.path.join(_HERE, "gadget_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src),
+                                                                     os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "CC=gcc"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_morton_key.restype = C.c_ulonglong
+        L.orc_peano_hilbert_key.restype = C.c_ulonglong
+        L.orc_tree_build.restype = C.c_void_p
+        L.orc_tree_build.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_double, C.c_int]
+        L.orc_tree_free.argtypes = [C.c_void_p]
+        L.orc_tree_numnodes.argtypes = [C.c_void_p]
+        L.orc_tree_dump.argtypes = [C.c_void_p] * 10
+        L.orc_tree_dump_particles.argtypes = [C.c_void_p] * 3
+        L.orc_update_hmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_gravity.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_gravity_shortrange.argtypes = L.orc_gravity.argtypes
+        L.orc_gravity_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_gravity_ewald.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_ewald_init.argtypes = [C.c_void_p, C.c_double]
+        L.orc_ewald_force.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_gravity_direct.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p]
+        L.orc_ngb_treefind_variable.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                C.c_double, C.c_void_p]
+        L.orc_ngb_treefind_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                             C.c_int, C.c_double, C.c_void_p]
+        L.orc_density_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                           C.c_void_p, C.c_void_p]
+        L.orc_density.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 14
+        L.orc_hydro.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13
+        L.orc_set_num_threads.argtypes = [C.c_int]
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def morton_key(x, y, z, bits=21):
+    return int(lib().orc_morton_key(int(x), int(y), int(z), int(bits)))
+
+
+def peano_hilbert_key(x, y, z, bits=21):
+    return int(lib().orc_peano_hilbert_key(int(x), int(y), int(z), int(bits)))
+
+
+def domain_extent(pos):
+    pos = _f64(pos)
+    corner = np.zeros(3)
+    center = np.zeros(3)
+    ln = C.c_double()
+    lib().orc_domain_extent.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib().orc_domain_extent(len(pos), _p(pos), _p(corner), _p(center), C.byref(ln))
+    return corner, center, ln.value
+
+
+_EWALD_CACHE = {}
+
+
+def ewald_table(boxsize=1.0, cache_dir=None):
+    """[3][65][65][65] correction-force table, scaled by 1/BoxSize^2 (forcetree.c:4402-4527).
+    Cached on disk because the CPU evaluation takes ~10 s on 8 cores."""
+    key = float(boxsize)
+    if key in _EWALD_CACHE:
+        return _EWALD_CACHE[key]
+    cache_dir = cache_dir or os.path.join(_HERE, "_cache")
+    fn = os.path.join(cache_dir, "ewald_oracle_box1.npy")
+    if os.path.exists(fn):
+        unit = np.load(fn)
+    else:
+        unit = np.zeros((3, EN + 1, EN + 1, EN + 1))
+        lib().orc_ewald_init(_p(unit), 1.0)
+        try:
+            os.makedirs(cache_dir, exist_ok=True)
+            np.save(fn, unit)
+        except OSError:
+            pass
+    tab = np.ascontiguousarray(unit / (boxsize * boxsize))
+    _EWALD_CACHE[key] = tab
+    return tab
+
+
+def ewald_force(i, j, k, x):
+    x = _f64(x)
+    f = np.zeros(3)
+    lib().orc_ewald_force(i, j, k, _p(x), _p(f))
+    return f
+
+
+class Tree:
+    """The reference-style insertion oct-tree over SoA particle arrays."""
+
+    def __init__(self, pos, vel, mass, ptype, soft, hsml=None, divvel=None, extent=None,
+                 toplevels=0):
+        self.pos = _f64(pos)
+        self.n = len(self.pos)
+        self.vel = _f64(vel) if vel is not None else np.zeros_like(self.pos)
+        self.mass = _f64(mass)
+        self.type = _i32(ptype)
+        self.soft = _f64(soft)
+        self.hsml = None if hsml is None else _f64(hsml)
+        self.divvel = None if divvel is None else _f64(divvel)
+        if extent is None:
+            extent = domain_extent(self.pos)
+        self.corner, self.center, self.len = _f64(extent[0]), _f64(extent[1]), float(extent[2])
+        self.h = lib().orc_tree_build(self.n, _p(self.pos), _p(self.vel), _p(self.mass),
+                                      _p(self.type), _p(self.hsml), _p(self.divvel),
+                                      _p(self.soft), _p(self.corner), _p(self.center),
+                                      self.len, int(toplevels))
+        if not self.h:
+            raise MemoryError("orc_tree_build failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tree_free(self.h)
+            self.h = None
+
+    @property
+    def numnodes(self):
+        return lib().orc_tree_numnodes(self.h)
+
+    def dump(self):
+        k = self.numnodes
+        out = dict(len=np.zeros(k), center=np.zeros((k, 3)), s=np.zeros((k, 3)), mass=np.zeros(k),
+                   sibling=np.zeros(k, np.int32), nextnode=np.zeros(k, np.int32),
+                   father=np.zeros(k, np.int32), multi=np.zeros(k, np.int32), hmax=np.zeros(k))
+        lib().orc_tree_dump(self.h, *[_p(out[x]) for x in
+                                      ("len", "center", "s", "mass", "sibling", "nextnode",
+                                       "father", "multi", "hmax")])
+        pn = np.zeros(self.n, np.int32)
+        pf = np.zeros(self.n, np.int32)
+        lib().orc_tree_dump_particles(self.h, _p(pn), _p(pf))
+        out["p_nextnode"] = pn
+        out["p_father"] = pf
+        return out
+
+    def update_hmax(self, active, hsml, divvel=None):
+        active = _i32(active)
+        self._hs = _f64(hsml)
+        self._dv = None if divvel is None else _f64(divvel)
+        lib().orc_update_hmax(self.h, len(active), _p(active), _p(self._hs), _p(self._dv))
+
+    # ---- gravity ----
+    def gravity(self, params, targets, oldacc, kind="newton", ewald_tab=None):
+        targets = _i32(targets)
+        oldacc = _f64(oldacc)
+        acc = np.zeros((len(targets), 3))
+        cost = np.zeros(len(targets), np.int32)
+        fn = {"newton": lib().orc_gravity, "shortrange": lib().orc_gravity_shortrange}[kind]
+        fn(self.h, C.byref(params), len(targets), _p(targets), _p(oldacc), _p(acc), _p(cost))
+        return acc, cost
+
+    def gravity_ewald_add(self, params, tab, targets, oldacc, acc, cost):
+        targets = _i32(targets)
+        oldacc = _f64(oldacc)
+        lib().orc_gravity_ewald(self.h, C.byref(params), _p(tab), len(targets), _p(targets),
+                                _p(oldacc), _p(acc), _p(cost))
+
+    def gravity_ext(self, params, tpos, ttype, toldacc):
+        tpos = _f64(tpos)
+        ttype = _i32(ttype)
+        toldacc = _f64(toldacc)
+        acc = np.zeros((len(tpos), 3))
+        cost = np.zeros(len(tpos), np.int32)
+        lib().orc_gravity_ext(self.h, C.byref(params), len(tpos), _p(tpos), _p(ttype),
+                              _p(toldacc), _p(acc), _p(cost))
+        return acc, cost
+
+    # ---- neighbours ----
+    def ngb_variable(self, c, h, periodic, boxsize):
+        c = _f64(c)
+        buf = np.zeros(self.n, np.int32)
+        k = lib().orc_ngb_treefind_variable(self.h, _p(c), float(h), int(periodic),
+                                            float(boxsize), _p(buf))
+        return buf[:k].copy()
+
+    def ngb_pairs(self, c, h, hsml, periodic, boxsize):
+        c = _f64(c)
+        hsml = _f64(hsml)
+        buf = np.zeros(self.n, np.int32)
+        k = lib().orc_ngb_treefind_pairs(self.h, _p(c), float(h), _p(hsml), int(periodic),
+                                         float(boxsize), _p(buf))
+        return buf[:k].copy()
+
+    # ---- SPH ----
+    def density_evaluate(self, params, target, h, velpred):
+        velpred = _f64(velpred)
+        out = np.zeros(7)
+        lib().orc_density_evaluate(self.h, C.byref(params), int(target), float(h), _p(velpred),
+                                   _p(out))
+        return out
+
+    def density(self, params, active, velpred, entropy, dtentropy, timebin, ti_begstep, hsml):
+        """Runs the h-iteration; returns dict of arrays sized n (gas entries meaningful)."""
+        n = self.n
+        active = _i32(active)
+        velpred = _f64(velpred)
+        entropy = _f64(entropy)
+        dtentropy = _f64(dtentropy)
+        timebin = _i32(timebin)
+        ti_begstep = _i32(ti_begstep)
+        out = dict(hsml=_f64(hsml).copy(), numngb=np.zeros(n), density=np.zeros(n),
+                   dhsmlfac=np.zeros(n), divvel=np.zeros(n), curlvel=np.zeros(n),
+                   pressure=np.zeros(n))
+        visits = C.c_longlong(0)
+        it = lib().orc_density(self.h, C.byref(params), len(active), _p(active), _p(velpred),
+                               _p(entropy), _p(dtentropy), _p(timebin), _p(ti_begstep),
+                               _p(out["hsml"]), _p(out["numngb"]), _p(out["density"]),
+                               _p(out["dhsmlfac"]), _p(out["divvel"]), _p(out["curlvel"]),
+                               _p(out["pressure"]), C.byref(visits))
+        out["iterations"] = it
+        out["ngb_visits"] = visits.value
+        return out
+
+    def hydro(self, params, active, velpred, hsml, density, pressure, dhsmlfac, divvel, curlvel,
+              timebin):
+        n = self.n
+        active = _i32(active)
+        arrs = [_f64(x) for x in (velpred, hsml, density, pressure, dhsmlfac, divvel, curlvel)]
+        timebin = _i32(timebin)
+        out = dict(hydroaccel=np.zeros((n, 3)), dtentropy=np.zeros(n), maxsignalvel=np.zeros(n))
+        npairs = C.c_longlong(0)
+        lib().orc_hydro(self.h, C.byref(params), len(active), _p(active), *[_p(a) for a in arrs],
+                        _p(timebin), _p(out["hydroaccel"]), _p(out["dtentropy"]),
+                        _p(out["maxsignalvel"]), C.byref(npairs))
+        out["npairs"] = npairs.value
+        return out
+
+
+def gravity_direct(pos, mass, ptype, soft, targets, unequal=False, periodic=False, boxsize=1.0,
+                   ewald_tab=None):
+    pos = _f64(pos)
+    mass = _f64(mass)
+    ptype = _i32(ptype)
+    soft = _f64(soft)
+    targets = _i32(targets)
+    acc = np.zeros((len(targets), 3))
+    lib().orc_gravity_direct(len(pos), _p(pos), _p(mass), _p(ptype), _p(soft), int(unequal),
+                             int(periodic), float(boxsize), _p(ewald_tab), len(targets),
+                             _p(targets), _p(acc))
+    return acc
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads():
+    return lib().orc_num_threads()
