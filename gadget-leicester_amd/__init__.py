@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
         hdeps = [hsrc, os.path.join(REPO_DIR, "include", "gadget_force.h"),
                  os.path.join(REPO_DIR, "include", "ghip.h"), LIBGHIP]
         if force or _newer(LIBHOST, hdeps):
-            cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-Wall",
+            cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=gnu99", "-Wall",
                    "-I", os.path.join(REPO_DIR, "include"), hsrc, "-o", LIBHOST,
                    "-L", PKG_DIR, "-lghip", "-Wl,-rpath,$ORIGIN", "-lm"]
             if verbose:

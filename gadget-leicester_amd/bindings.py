@@ -55,7 +55,7 @@ class HydroParams(C.Structure):
     _fields_ = [("ArtBulkViscConst", C.c_double), ("BoxSize", C.c_double), ("periodic", C.c_int),
                 ("ComovingIntegrationOn", C.c_int), ("hubble_a2", C.c_double),
                 ("fac_mu", C.c_double), ("fac_vsic_fix", C.c_double),
-                ("Timebase_interval", C.c_double)]
+                ("Timebase_interval", C.c_double), ("raw_dtentropy", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -65,7 +65,8 @@ class Stats(C.Structure):
                 ("hydro_pairs", C.c_longlong), ("hydro_targets", C.c_longlong),
                 ("tree_nodes", C.c_int), ("gastree_nodes", C.c_int),
                 ("ms_tree", C.c_float), ("ms_grav", C.c_float), ("ms_ewald", C.c_float),
-                ("ms_dens", C.c_float), ("ms_hmax", C.c_float), ("ms_hydro", C.c_float)]
+                ("ms_dens", C.c_float), ("ms_hmax", C.c_float), ("ms_hydro", C.c_float),
+                ("grav_wave_steps", C.c_longlong), ("ewald_wave_steps", C.c_longlong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -524,8 +524,10 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   ghip_stats &S = ctx->stats;
   if(ctx->counters.p)
     {
-      unsigned long long c[8];
+      unsigned long long c[16];
       HIPCHK(hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+      S.grav_wave_steps = (long long) c[8];
+      S.ewald_wave_steps = (long long) c[9];
       S.grav_interactions = (long long) c[0];
       S.ewald_interactions = (long long) c[1];
       S.dens_neighbours = (long long) c[4];

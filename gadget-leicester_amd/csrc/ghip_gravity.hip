@@ -24,6 +24,7 @@ struct GravK
   double errtol;       // ErrTolForceAcc
   double boxsize, boxhalf;
   int periodic, unequal;
+  int debug_steps;     // GHIP_DEBUG_STEPS=1: GRAVCOST receives the wave's visited-element count
   double rcut, rcut2, asmthfac;  // shortrange
   double fac_intp;     // ewald: 2*EN/BoxSize
 };
@@ -124,11 +125,13 @@ k_grav_walk(int nelem, const double4 *__restrict__ xm, const double4 *__restrict
   double acc_x = 0, acc_y = 0, acc_z = 0;
   int nint = 0;
   int my_skip = valid ? 0 : 0x7fffffff;
+  unsigned int steps = 0;
 
   int e = 0;
   while(e < nelem)
     {
       e = __builtin_amdgcn_readfirstlane(e);
+      steps++;
       const double4 v = xm[e];
       const int4 k = lk[e];
       const bool act = (e >= my_skip);
@@ -278,11 +281,13 @@ k_grav_walk(int nelem, const double4 *__restrict__ xm, const double4 *__restrict
       ax[ti] = acc_x;
       ay[ti] = acc_y;
       az[ti] = acc_z;
-      cost[ti] = nint;
+      cost[ti] = p.debug_steps ? (int) steps : nint;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) nint);
   if(lane == 0 && tot)
     atomicAdd(counter, tot);
+  if(lane == 0)
+    atomicAdd(counter + 8, (unsigned long long) steps);
 }
 
 // results from target order to host order; EWALD adds (forcetree.c:3190-3193)
@@ -490,6 +495,7 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.rcut2 = p->Rcut * p->Rcut;
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
   k.fac_intp = (p->BoxSize > 0) ? 2 * GHIP_EN / p->BoxSize : 0;
+  k.debug_steps = getenv("GHIP_DEBUG_STEPS") ? 1 : 0;
   if(walk == GHIP_WALK_SHORTRANGE)
     {
       if(!(p->Asmth > 0) || !(p->Rcut > 0))
@@ -577,6 +583,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
+  HIPCHK(hipMemsetAsync(counter + 8, 0, 8, st));
 
   // OldAcc in tree order (forcetree.c:1850: aold = ErrTolForceAcc * P[target].OldAcc)
   GCHK(ghip_gather_f64(ctx, n, P<int>(ctx->gt.perm), P<double>(ctx->f[GHIP_F_OLDACC]),

@@ -572,7 +572,7 @@ extern "C" int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double h
 struct HydK
 {
   double visc_const, hubble_a2, fac_mu, fac_vsic_fix, timebase;
-  int comoving;
+  int comoving, raw;
 };
 
 struct HydAcc
@@ -739,7 +739,8 @@ k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
       o_acc[(size_t) ngas + i] = A.ay;
       o_acc[2 * (size_t) ngas + i] = A.az;
       // hydra.c:583
-      o_dtent[i] = A.dtent * (GAMMA_MINUS1 / (K.hubble_a2 * pow(T.rho, GAMMA_MINUS1)));
+      o_dtent[i] = K.raw ? A.dtent
+                         : A.dtent * (GAMMA_MINUS1 / (K.hubble_a2 * pow(T.rho, GAMMA_MINUS1)));
       o_maxsig[i] = A.maxsig;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.np);
@@ -767,7 +768,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
-            p->ComovingIntegrationOn};
+            p->ComovingIntegrationOn, p->raw_dtentropy};
   HIPCHK(hipEventRecord(ctx->ev[10], st));
   k_hydro<<<cdiv(nt, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
     t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<double>(ctx->gp),

@@ -1,0 +1,748 @@
+/*
+ * gadget_force.c -- host C glue: the reference's force-path call surface on top of libghip.so.
+ *
+ * Mirrors, function by function, what accel.c (accel.c:27-313) and init.c:791 call:
+ * gravity_tree() (gravtree.c:27-828), density() (density.c:89-704), force_update_hmax()
+ * (forcetree.c:1661-1786), hydro_force() (hydra.c:145-813) plus the per-target *_evaluate and
+ * ngb_treefind_* entry points (forcetree.h:31-35, 107-111; proto.h:205, 229-230).
+ *
+ * The batched drivers replace the reference's `for(i = FirstActiveParticle; i >= 0;
+ * i = NextActiveParticle[i])` loops (gravtree.c:130, density.c:174, hydra.c:257) by one device
+ * launch over the whole active list.  The per-target entry points run a batch of one on the GPU.
+ * Nothing here computes forces on the CPU.
+ */
+#include "gadget_force.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ---- globals (allvars.c) ---- */
+struct particle_data *P = NULL;
+struct sph_particle_data *SphP = NULL;
+struct global_data_all_processes All;
+int NumPart = 0, N_gas = 0;
+int FirstActiveParticle = -1, *NextActiveParticle = NULL;
+int TreeReconstructFlag = 1;
+double DomainCorner[3], DomainCenter[3], DomainLen = 0, DomainFac = 0;
+int *Ngblist = NULL;
+struct gravdata_in *GravDataGet = NULL;
+struct gravdata_out *GravDataResult = NULL;
+int ThisTask = 0, NTask = 1;
+double CPU_Step_Treewalk = 0, CPU_Step_Treebuild = 0, CPU_Step_Density = 0, CPU_Step_Hydro = 0,
+  CPU_Step_Hmaxupdate = 0;
+
+static ghip_ctx *Ctx = NULL;
+static struct gadget_force_config Cfg;
+static void (*EndrunHandler)(int) = NULL;
+static int DeviceFresh = 0;      /* device copy of P/SphP matches the host arrays */
+static int TreeOnDevice = 0;
+static int Phase = 0;            /* 1 after gravity_tree(), 2 after density(): accel.c:61-106 order */
+static int *ActiveBuf = NULL;
+static int ActiveCap = 0;
+static int NgblistCap = 0;
+static char ErrBuf[1200];
+
+static double wallclock(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* endrun.c:23-38 */
+void endrun(int ierr)
+{
+  if(EndrunHandler)
+    {
+      EndrunHandler(ierr);
+      return;
+    }
+  if(ierr)
+    {
+      printf("task %d: endrun called with an error level of %d\n\n\n", ThisTask, ierr);
+      fflush(stdout);
+      abort();
+    }
+  exit(0);
+}
+
+void gadget_force_set_endrun(void (*handler)(int code))
+{
+  EndrunHandler = handler;
+}
+
+const char *gadget_force_last_error(void)
+{
+  return ErrBuf;
+}
+
+ghip_ctx *gadget_force_ctx(void)
+{
+  return Ctx;
+}
+
+void gadget_force_mark_dirty(void)
+{
+  DeviceFresh = 0;
+}
+
+/* a failing device call ends the run the way the reference ends it: endrun(code).  Codes 9xxxx
+ * are reserved for this library. */
+static int chk(int rc, const char *where)
+{
+  if(rc == GHIP_OK)
+    return 0;
+  snprintf(ErrBuf, sizeof(ErrBuf), "%s: %d %s", where, rc, Ctx ? ghip_last_error(Ctx) : "");
+  fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+  endrun(rc == GHIP_ENOCONV ? 1155 : -rc);
+  return rc;
+}
+
+int gadget_force_init(const struct gadget_force_config *cfg)
+{
+  if(!cfg)
+    return GHIP_EINVAL;
+  if(Ctx)
+    gadget_force_finalize();
+  Cfg = *cfg;
+  ErrBuf[0] = 0;
+  int rc = ghip_create(cfg->device, &Ctx);
+  if(rc != GHIP_OK)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "ghip_create(device %d) failed: %d (no GPU: this library "
+               "has no CPU path)", cfg->device, rc);
+      Ctx = NULL;
+      return rc;
+    }
+  DeviceFresh = 0;
+  TreeOnDevice = 0;
+  return GHIP_OK;
+}
+
+void gadget_force_finalize(void)
+{
+  if(Ctx)
+    ghip_destroy(Ctx);
+  Ctx = NULL;
+  free(ActiveBuf);
+  ActiveBuf = NULL;
+  ActiveCap = 0;
+  free(Ngblist);
+  Ngblist = NULL;
+  NgblistCap = 0;
+  DeviceFresh = 0;
+  TreeOnDevice = 0;
+}
+
+void gadget_force_layout(ghip_layout *lay)
+{
+  memset(lay, 0xff, sizeof(*lay)); /* every offset -1 */
+  lay->p_stride = (int) sizeof(struct particle_data);
+  lay->p_pos = (int) offsetof(struct particle_data, Pos);
+  lay->p_vel = (int) offsetof(struct particle_data, Vel);
+  lay->p_mass = (int) offsetof(struct particle_data, Mass);
+  lay->p_gravaccel = (int) offsetof(struct particle_data, g);
+  lay->p_oldacc = (int) offsetof(struct particle_data, OldAcc);
+  lay->p_gravcost = (int) offsetof(struct particle_data, GravCost);
+  lay->p_ti_begstep = (int) offsetof(struct particle_data, Ti_begstep);
+  lay->p_type = (int) offsetof(struct particle_data, Type);
+  lay->p_timebin = (int) offsetof(struct particle_data, TimeBin);
+  lay->p_hsml = -1;
+  lay->p_numngb = -1;
+  lay->s_stride = (int) sizeof(struct sph_particle_data);
+  lay->s_entropy = (int) offsetof(struct sph_particle_data, Entropy);
+  lay->s_pressure = (int) offsetof(struct sph_particle_data, Pressure);
+  lay->s_velpred = (int) offsetof(struct sph_particle_data, VelPred);
+  lay->s_maxsignalvel = (int) offsetof(struct sph_particle_data, MaxSignalVel);
+  lay->s_density = (int) offsetof(struct sph_particle_data, d);
+  lay->s_dtentropy = (int) offsetof(struct sph_particle_data, e);
+  lay->s_hydroaccel = (int) offsetof(struct sph_particle_data, a);
+  lay->s_dhsmlfac = (int) offsetof(struct sph_particle_data, h);
+  lay->s_divvel = (int) offsetof(struct sph_particle_data, v);
+  lay->s_curlvel = (int) offsetof(struct sph_particle_data, r);
+  lay->s_hsml = (int) offsetof(struct sph_particle_data, Hsml);
+  lay->s_numngb = (int) offsetof(struct sph_particle_data, n);
+}
+
+/* gravtree.c:835-884 */
+void set_softenings(void)
+{
+  const double soft[6] = { All.SofteningGas, All.SofteningHalo, All.SofteningDisk,
+    All.SofteningBulge, All.SofteningStars, All.SofteningBndry };
+  const double maxphys[6] = { All.SofteningGasMaxPhys, All.SofteningHaloMaxPhys,
+    All.SofteningDiskMaxPhys, All.SofteningBulgeMaxPhys, All.SofteningStarsMaxPhys,
+    All.SofteningBndryMaxPhys };
+  for(int i = 0; i < 6; i++)
+    {
+      if(All.ComovingIntegrationOn && soft[i] * All.Time > maxphys[i])
+        All.SofteningTable[i] = maxphys[i] / All.Time;
+      else
+        All.SofteningTable[i] = soft[i];
+    }
+  for(int i = 0; i < 6; i++)
+    All.ForceSoftening[i] = 2.8 * All.SofteningTable[i];
+  All.MinGasHsml = All.MinGasHsmlFractional * All.ForceSoftening[0];
+}
+
+/* darkenergy.c:389-409 without DARKENERGY */
+double hubble_function(double a)
+{
+  double hubble_a = All.Omega0 / (a * a * a) + (1 - All.Omega0 - All.OmegaLambda) / (a * a) +
+    All.OmegaLambda;
+  return All.Hubble * sqrt(hubble_a);
+}
+
+/* domain.c:1972-2014 (single rank) */
+void domain_findExtent(void)
+{
+  double xmin[3] = { 1e300, 1e300, 1e300 }, xmax[3] = { -1e300, -1e300, -1e300 };
+  for(int i = 0; i < NumPart; i++)
+    for(int j = 0; j < 3; j++)
+      {
+        if(xmin[j] > P[i].Pos[j])
+          xmin[j] = P[i].Pos[j];
+        if(xmax[j] < P[i].Pos[j])
+          xmax[j] = P[i].Pos[j];
+      }
+  double len = 0;
+  for(int j = 0; j < 3; j++)
+    if(xmax[j] - xmin[j] > len)
+      len = xmax[j] - xmin[j];
+  len *= 1.001;
+  for(int j = 0; j < 3; j++)
+    {
+      DomainCenter[j] = 0.5 * (xmin[j] + xmax[j]);
+      DomainCorner[j] = 0.5 * (xmin[j] + xmax[j]) - 0.5 * len;
+    }
+  DomainLen = len;
+  DomainFac = 1.0 / len * (((peanokey) 1) << (BITS_PER_DIMENSION));
+}
+
+/* peano.c:320-333 */
+peanokey morton_key(int x, int y, int z, int bits)
+{
+  peanokey m = 0;
+  for(int b = bits - 1; b >= 0; b--)
+    {
+      m <<= 3;
+      m += (peanokey) ((((z >> b) & 1) << 2) + (((y >> b) & 1) << 1) + ((x >> b) & 1));
+    }
+  return m;
+}
+
+/* peano.c:300-316: the reference's curve generated from its definition (base octant order +
+ * per-octant cube symmetry) instead of its 48-state tables; see ghip_tree.hip */
+peanokey peano_hilbert_key(int x, int y, int z, int bits)
+{
+  static const unsigned char base[8] = { 0, 7, 1, 6, 3, 4, 2, 5 };
+  static const unsigned char cperm[8][3] = { {0, 2, 1}, {0, 2, 1}, {2, 1, 0}, {2, 1, 0},
+  {0, 1, 2}, {0, 1, 2}, {2, 1, 0}, {2, 1, 0} };
+  static const unsigned char cflip[8][3] = { {0, 0, 0}, {0, 1, 1}, {0, 0, 0}, {1, 0, 1},
+  {1, 1, 0}, {1, 1, 0}, {0, 0, 0}, {1, 0, 1} };
+  int perm[3] = { 0, 1, 2 }, flip[3] = { 0, 0, 0 };
+  peanokey key = 0;
+  for(int b = bits - 1; b >= 0; b--)
+    {
+      int v[3] = { (x >> b) & 1, (y >> b) & 1, (z >> b) & 1 };
+      int w[3];
+      for(int i = 0; i < 3; i++)
+        w[i] = v[perm[i]] ^ flip[i];
+      int local = w[0] * 4 + w[1] * 2 + w[2];
+      key = (key << 3) | base[local];
+      int np[3], nf[3];
+      for(int i = 0; i < 3; i++)
+        {
+          np[i] = perm[cperm[local][i]];
+          nf[i] = flip[cperm[local][i]] ^ cflip[local][i];
+        }
+      memcpy(perm, np, sizeof(perm));
+      memcpy(flip, nf, sizeof(flip));
+    }
+  return key;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+static int need_ctx(const char *who)
+{
+  if(Ctx)
+    return 0;
+  snprintf(ErrBuf, sizeof(ErrBuf), "%s: gadget_force_init() has not succeeded (no GPU context)",
+           who);
+  fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+  endrun(90005);
+  return -1;
+}
+
+static int upload_particles(void)
+{
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  if(chk(ghip_upload_aos(Ctx, P, SphP, &lay, NumPart, N_gas), "ghip_upload_aos"))
+    return -1;
+  DeviceFresh = 1;
+  TreeOnDevice = 0;
+  return 0;
+}
+
+/* the active list as the reference threads it (run.c:300-320) */
+static int collect_active(int gas_only)
+{
+  int n = 0;
+  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+    {
+      if(gas_only && !(i < N_gas && P[i].Type == 0))
+        continue;
+      if(n >= ActiveCap)
+        {
+          int nc = ActiveCap ? 2 * ActiveCap : 1024;
+          int *nb = (int *) realloc(ActiveBuf, (size_t) nc * sizeof(int));
+          if(!nb)
+            {
+              endrun(90003);
+              return -1;
+            }
+          ActiveBuf = nb;
+          ActiveCap = nc;
+        }
+      ActiveBuf[n++] = i;
+    }
+  return n;
+}
+
+static void fill_grav_params(ghip_grav_params *g)
+{
+  memset(g, 0, sizeof(*g));
+  g->ErrTolTheta = All.ErrTolTheta;
+  g->ErrTolForceAcc = All.ErrTolForceAcc;
+  for(int i = 0; i < 6; i++)
+    g->ForceSoftening[i] = All.ForceSoftening[i];
+  g->BoxSize = All.BoxSize;
+  g->periodic = Cfg.periodic;
+  g->unequal_softenings = Cfg.unequal_softenings;
+  g->Rcut = All.Rcut[0];
+  g->Asmth = All.Asmth[0];
+}
+
+static void fill_dens_params(ghip_dens_params *d)
+{
+  memset(d, 0, sizeof(*d));
+  d->DesNumNgb = All.DesNumNgb;
+  d->MaxNumNgbDeviation = All.MaxNumNgbDeviation;
+  d->MinGasHsml = All.MinGasHsml;
+  d->BoxSize = All.BoxSize;
+  d->periodic = Cfg.periodic;
+  d->Ti_Current = All.Ti_Current;
+  d->Timebase_interval = All.Timebase_interval;
+  d->MaxIter = 150; /* MAXITER */
+}
+
+static void fill_hydro_params(ghip_hydro_params *h, int raw)
+{
+  memset(h, 0, sizeof(*h));
+  h->ArtBulkViscConst = All.ArtBulkViscConst;
+  h->BoxSize = All.BoxSize;
+  h->periodic = Cfg.periodic;
+  h->ComovingIntegrationOn = All.ComovingIntegrationOn;
+  if(All.ComovingIntegrationOn)
+    {
+      /* hydra.c:192-208 */
+      double hubble_a = hubble_function(All.Time);
+      h->hubble_a2 = All.Time * All.Time * hubble_a;
+      h->fac_mu = pow(All.Time, 3 * (GAMMA - 1) / 2) / All.Time;
+      h->fac_vsic_fix = hubble_a * pow(All.Time, 3 * GAMMA_MINUS1);
+    }
+  else
+    h->hubble_a2 = h->fac_mu = h->fac_vsic_fix = 1.0;
+  h->Timebase_interval = All.Timebase_interval;
+  h->raw_dtentropy = raw;
+}
+
+/* forcetree.c:67-103: (re)build the tree over the current particles */
+int force_treebuild(int npart, void *mp)
+{
+  (void) mp;
+  if(need_ctx("force_treebuild"))
+    return -1;
+  double t0 = wallclock();
+  if(!DeviceFresh)
+    if(upload_particles())
+      return -1;
+  if(DomainLen <= 0)
+    domain_findExtent();
+  if(chk(ghip_tree_build(Ctx, DomainCorner, DomainCenter, DomainLen, All.ForceSoftening),
+         "ghip_tree_build"))
+    return -1;
+  ghip_sync(Ctx);
+  TreeOnDevice = 1;
+  CPU_Step_Treebuild += wallclock() - t0;
+  ghip_stats st;
+  ghip_get_stats(Ctx, &st);
+  (void) npart;
+  return st.tree_nodes;
+}
+
+/* forcetree.c:4402-4527 */
+void ewald_init(void)
+{
+  if(need_ctx("ewald_init"))
+    return;
+  chk(ghip_ewald_init(Ctx, All.BoxSize), "ghip_ewald_init");
+}
+
+static int ensure_tree(void)
+{
+  if(!DeviceFresh)
+    {
+      if(upload_particles())
+        return -1;
+    }
+  if(TreeReconstructFlag || !TreeOnDevice)
+    {
+      if(force_treebuild(NumPart, NULL) < 0)
+        return -1;
+      TreeReconstructFlag = 0;
+    }
+  return 0;
+}
+
+/* gravtree.c:27-828 */
+void gravity_tree(void)
+{
+  if(need_ctx("gravity_tree"))
+    return;
+  double t0 = wallclock();
+  /* gravtree.c:55-56 */
+  if(All.ComovingIntegrationOn)
+    set_softenings();
+  /* positions were drifted since the last force computation: refresh the device copy.  The
+   * reference reuses a drifted tree on sub-steps (forcetree.c:1356-1452); this path rebuilds. */
+  DeviceFresh = 0;
+  TreeOnDevice = 0;
+  if(ensure_tree())
+    return;
+  int nact = collect_active(0);
+  if(nact < 0)
+    return;
+  if(chk(ghip_set_active(Ctx, nact == NumPart ? NULL : ActiveBuf, nact == NumPart ? 0 : nact),
+         "ghip_set_active"))
+    return;
+  ghip_grav_params g;
+  fill_grav_params(&g);
+  /* gravtree.c:96-100, 130-168: PMGRID -> short-range walk; PERIODIC && !PMGRID -> a second,
+   * Ewald-correction walk */
+  int walk = Cfg.pmgrid ? GHIP_WALK_SHORTRANGE : GHIP_WALK_NEWTON;
+  if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
+    return;
+  if(Cfg.periodic && !Cfg.pmgrid)
+    if(chk(ghip_gravity(Ctx, &g, GHIP_WALK_EWALD), "ghip_gravity(ewald)"))
+      return;
+  /* gravtree.c:381-403 */
+  if(chk(ghip_gravity_finish(Ctx, All.G), "ghip_gravity_finish"))
+    return;
+  if(All.TypeOfOpeningCriterion == 1)
+    All.ErrTolTheta = 0; /* gravtree.c:396-397 */
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))
+    return;
+  All.TotNumOfForces += nact;
+  Phase = 1;
+  CPU_Step_Treewalk += wallclock() - t0;
+}
+
+/* density.c:1035-1053 */
+int density_isactive(int n)
+{
+  if(P[n].TimeBin < 0)
+    return 0;
+  if(P[n].Type == 5)
+    return 1;
+  if(P[n].Type == 2)
+    return 1;
+  if(P[n].Type == 0)
+    return 1;
+  return 0;
+}
+
+/* density.c:89-704 */
+void density(void)
+{
+  if(need_ctx("density"))
+    return;
+  double t0 = wallclock();
+  /* directly after gravity_tree() (accel.c:61-84) the device copy is current; a stand-alone
+   * call (init.c:791) re-reads P/SphP */
+  if(Phase != 1)
+    DeviceFresh = 0;
+  if(ensure_tree())
+    return;
+  int nact = collect_active(1);
+  if(nact < 0)
+    return;
+  /* an empty list must not mean "all": give the device a real (possibly empty) list */
+  if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
+    return;
+  ghip_dens_params d;
+  fill_dens_params(&d);
+  if(chk(ghip_density(Ctx, &d), "ghip_density"))
+    return;
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 0, 1, 0), "ghip_download_aos"))
+    return;
+  Phase = 2;
+  CPU_Step_Density += wallclock() - t0;
+}
+
+/* forcetree.c:1661-1786 */
+void force_update_hmax(void)
+{
+  if(need_ctx("force_update_hmax"))
+    return;
+  double t0 = wallclock();
+  chk(ghip_update_hmax(Ctx), "ghip_update_hmax");
+  CPU_Step_Hmaxupdate += wallclock() - t0;
+}
+
+/* hydra.c:145-813 */
+void hydro_force(void)
+{
+  if(need_ctx("hydro_force"))
+    return;
+  double t0 = wallclock();
+  if(Phase != 2)
+    DeviceFresh = 0;
+  if(ensure_tree())
+    return;
+  int nact = collect_active(1);
+  if(nact < 0)
+    return;
+  if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
+    return;
+  ghip_hydro_params h;
+  fill_hydro_params(&h, 0);
+  if(chk(ghip_hydro(Ctx, &h), "ghip_hydro"))
+    return;
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 0, 0, 1), "ghip_download_aos"))
+    return;
+  Phase = 0;
+  CPU_Step_Hydro += wallclock() - t0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-target surface: a batch of one on the device
+ * ---------------------------------------------------------------------------------------- */
+static int treeevaluate_one(int target, int mode, int *nexport, int walk)
+{
+  if(need_ctx("force_treeevaluate"))
+    return -1;
+  if(ensure_tree())
+    return -1;
+  ghip_grav_params g;
+  fill_grav_params(&g);
+  if(mode == 0)
+    {
+      if(target < 0 || target >= NumPart)
+        {
+          endrun(90002);
+          return -1;
+        }
+      /* results of the device's previous state for this target are needed for the "+=" of the
+       * Ewald walk (forcetree.c:3190-3193) */
+      static double *acc3 = NULL;
+      static int *cost = NULL;
+      static int cap = 0;
+      if(cap < NumPart)
+        {
+          acc3 = (double *) realloc(acc3, (size_t) NumPart * 3 * sizeof(double));
+          cost = (int *) realloc(cost, (size_t) NumPart * sizeof(int));
+          cap = NumPart;
+        }
+      if(walk == GHIP_WALK_EWALD)
+        {
+          /* seed the device result with the host's current partial sum */
+          if(chk(ghip_get_field(Ctx, GHIP_F_GRAVACCEL, acc3), "ghip_get_field") ||
+             chk(ghip_get_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_get_field"))
+            return -1;
+          for(int k = 0; k < 3; k++)
+            acc3[3 * (size_t) target + k] = P[target].g.dGravAccel[k];
+          cost[target] = (int) P[target].GravCost;
+          if(chk(ghip_set_field(Ctx, GHIP_F_GRAVACCEL, acc3), "ghip_set_field") ||
+             chk(ghip_set_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_set_field"))
+            return -1;
+        }
+      if(chk(ghip_set_active(Ctx, &target, 1), "ghip_set_active"))
+        return -1;
+      if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
+        return -1;
+      if(chk(ghip_get_field(Ctx, GHIP_F_GRAVACCEL, acc3), "ghip_get_field") ||
+         chk(ghip_get_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_get_field"))
+        return -1;
+      /* forcetree.c:2277-2293 */
+      int before = (int) P[target].GravCost;
+      for(int k = 0; k < 3; k++)
+        P[target].g.dGravAccel[k] = acc3[3 * (size_t) target + k];
+      P[target].GravCost = (float) cost[target];
+      return (walk == GHIP_WALK_EWALD) ? cost[target] - before : cost[target];
+    }
+  /* mode 1: an imported target, GravDataGet[target] -> GravDataResult[target]
+   * (forcetree.c:1862-1880, 2296-2314).  Single rank: the whole local tree is walked. */
+  if(!GravDataGet || !GravDataResult)
+    {
+      endrun(90002);
+      return -1;
+    }
+  double pos[3] = { GravDataGet[target].Pos[0], GravDataGet[target].Pos[1],
+    GravDataGet[target].Pos[2] };
+  int type = Cfg.unequal_softenings ? GravDataGet[target].Type : P[0].Type; /* forcetree.c:1868-1872 */
+  double oldacc = GravDataGet[target].OldAcc, acc[3];
+  int nint = 0;
+  if(chk(ghip_gravity_ext(Ctx, &g, walk, 1, pos, &type, &oldacc, acc, &nint), "ghip_gravity_ext"))
+    return -1;
+  for(int k = 0; k < 3; k++)
+    GravDataResult[target].Acc[k] = acc[k];
+  GravDataResult[target].Ninteractions = nint;
+  if(nexport)
+    *nexport = 1; /* nodesinlist */
+  return nint;
+}
+
+int force_treeevaluate(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nsend_local;
+  return treeevaluate_one(target, mode, nexport, GHIP_WALK_NEWTON);
+}
+
+int force_treeevaluate_shortrange(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nsend_local;
+  return treeevaluate_one(target, mode, nexport, GHIP_WALK_SHORTRANGE);
+}
+
+int force_treeevaluate_ewald_correction(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nsend_local;
+  int c = treeevaluate_one(target, mode, nexport, GHIP_WALK_EWALD);
+  return c < 0 ? c : 0;
+}
+
+/* density.c:711-1029, mode 0: raw sums into the d-unions (density.c:942-989) */
+int density_evaluate(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nexport;
+  (void) nsend_local;
+  if(need_ctx("density_evaluate"))
+    return -1;
+  if(mode != 0 || target < 0 || target >= N_gas)
+    {
+      endrun(90002);
+      return -1;
+    }
+  if(ensure_tree())
+    return -1;
+  ghip_dens_params d;
+  fill_dens_params(&d);
+  double out7[7];
+  if(chk(ghip_density_evaluate(Ctx, &d, target, PPP[target].Hsml, out7), "ghip_density_evaluate"))
+    return -1;
+  SphP[target].d.dDensity = out7[0];
+  PPP[target].n.dNumNgb = out7[1];
+  SphP[target].h.dDhsmlDensityFactor = out7[2];
+  SphP[target].v.dDivVel = out7[3];
+  SphP[target].r.dRot[0] = out7[4];
+  SphP[target].r.dRot[1] = out7[5];
+  SphP[target].r.dRot[2] = out7[6];
+  return 0;
+}
+
+/* hydra.c:822-1995, mode 0: raw sums (hydra.c:1931-1940) */
+int hydro_evaluate(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nexport;
+  (void) nsend_local;
+  if(need_ctx("hydro_evaluate"))
+    return -1;
+  if(mode != 0 || target < 0 || target >= N_gas)
+    {
+      endrun(90002);
+      return -1;
+    }
+  if(ensure_tree())
+    return -1;
+  if(chk(ghip_set_active(Ctx, &target, 1), "ghip_set_active"))
+    return -1;
+  ghip_hydro_params h;
+  fill_hydro_params(&h, 1);
+  if(chk(ghip_hydro(Ctx, &h), "ghip_hydro"))
+    return -1;
+  static double *buf = NULL;
+  static int cap = 0;
+  if(cap < N_gas)
+    {
+      buf = (double *) realloc(buf, (size_t) N_gas * 3 * sizeof(double));
+      cap = N_gas;
+    }
+  if(chk(ghip_get_field(Ctx, GHIP_F_HYDROACCEL, buf), "ghip_get_field"))
+    return -1;
+  for(int k = 0; k < 3; k++)
+    SphP[target].a.dHydroAccel[k] = buf[3 * (size_t) target + k];
+  if(chk(ghip_get_field(Ctx, GHIP_F_DTENTROPY, buf), "ghip_get_field"))
+    return -1;
+  SphP[target].e.dDtEntropy = buf[target];
+  if(chk(ghip_get_field(Ctx, GHIP_F_MAXSIGNALVEL, buf), "ghip_get_field"))
+    return -1;
+  SphP[target].MaxSignalVel = buf[target];
+  return 0;
+}
+
+static int ngb_find(MyDouble c[3], MyFloat hsml, int *startnode, int mode, int pairs)
+{
+  if(need_ctx("ngb_treefind"))
+    return -1;
+  if(mode != 0)
+    {
+      endrun(23131); /* ngb.c:92: pseudo-particle handling is not available in mode 1 */
+      return -1;
+    }
+  if(ensure_tree())
+    return -1;
+  if(NgblistCap < NumPart)
+    {
+      /* density.c:143 / hydra.c:230: Ngblist holds up to NumPart indices */
+      Ngblist = (int *) realloc(Ngblist, (size_t) (NumPart > 0 ? NumPart : 1) * sizeof(int));
+      NgblistCap = NumPart;
+    }
+  int nfound = 0;
+  if(chk(ghip_ngb_treefind(Ctx, c, hsml, pairs, Cfg.periodic, All.BoxSize, Ngblist, NgblistCap,
+                           &nfound), "ghip_ngb_treefind"))
+    return -1;
+  if(startnode)
+    *startnode = -1;
+  return nfound;
+}
+
+/* ngb.c:169-297 */
+int ngb_treefind_variable(MyDouble searchcenter[3], MyFloat hsml, int target, int *startnode,
+                          int mode, int *nexport, int *nsend_local)
+{
+  (void) target;
+  (void) nexport;
+  (void) nsend_local;
+  return ngb_find(searchcenter, hsml, startnode, mode, 0);
+}
+
+/* ngb.c:32-160 */
+int ngb_treefind_pairs(MyDouble searchcenter[3], MyFloat hsml, int target, int *startnode,
+                       int mode, int *nexport, int *nsend_local)
+{
+  (void) target;
+  (void) nexport;
+  (void) nsend_local;
+  return ngb_find(searchcenter, hsml, startnode, mode, 1);
+}

@@ -1,0 +1,179 @@
+"""ctypes view of libgadget_force.so (include/gadget_force.h): the reference's own call surface
+(gravity_tree(), density(), force_treeevaluate(), ...) on its own global AoS arrays.
+
+Used by the parity tests so that they read like tests of the reference's functions, and by
+INTEGRATION.md as the worked example of the binding.  No CPU fallback.
+"""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+
+_pkg = importlib.import_module(__package__)
+
+# struct particle_data (112 B) / sph_particle_data (184 B), minimal periodic flag set
+P_DTYPE = np.dtype({
+    "names": ["Pos", "Vel", "Mass", "ID", "GravAccel", "OldAcc", "GravCost", "Ti_begstep",
+              "Ti_current", "Type", "TimeBin"],
+    "formats": [("f8", 3), ("f8", 3), "f8", "u4", ("f8", 3), "f8", "f4", "i4", "i4", "i2", "i2"],
+    "offsets": [0, 24, 48, 56, 64, 88, 96, 100, 104, 108, 110],
+    "itemsize": 112})
+
+SPH_DTYPE = np.dtype({
+    "names": ["Entropy", "Pressure", "VelPred", "MaxSignalVel", "Density", "DtEntropy",
+              "HydroAccel", "DhsmlDensityFactor", "DivVel", "Rot", "Hsml", "Left", "Right",
+              "NumNgb", "Injected_BH_Energy"],
+    "formats": ["f8", "f8", ("f8", 3), "f8", "f8", "f8", ("f8", 3), "f8", "f8", ("f8", 3), "f8",
+                "f8", "f8", "f8", "f8"],
+    "offsets": [0, 8, 16, 40, 48, 56, 64, 88, 96, 104, 128, 136, 144, 152, 160],
+    "itemsize": 184})
+
+GRAVDATA_IN = np.dtype({"names": ["Pos", "Type", "OldAcc", "NodeList"],
+                        "formats": [("f8", 3), "i4", "f8", ("i4", 8)],
+                        "offsets": [0, 24, 32, 40], "itemsize": 72})
+GRAVDATA_OUT = np.dtype({"names": ["Acc", "Ninteractions"], "formats": [("f8", 3), "i4"],
+                         "offsets": [0, 24], "itemsize": 32})
+
+
+class AllStruct(C.Structure):
+    _fields_ = [("MaxPart", C.c_int), ("G", C.c_double), ("ErrTolTheta", C.c_double),
+                ("ErrTolForceAcc", C.c_double), ("TypeOfOpeningCriterion", C.c_int),
+                ("BoxSize", C.c_double), ("DesNumNgb", C.c_double),
+                ("MaxNumNgbDeviation", C.c_double), ("MinGasHsmlFractional", C.c_double),
+                ("MinGasHsml", C.c_double), ("ArtBulkViscConst", C.c_double),
+                ("Ti_Current", C.c_int), ("Timebase_interval", C.c_double), ("Time", C.c_double),
+                ("ComovingIntegrationOn", C.c_int), ("Hubble", C.c_double),
+                ("Omega0", C.c_double), ("OmegaLambda", C.c_double),
+                ("SofteningGas", C.c_double), ("SofteningHalo", C.c_double),
+                ("SofteningDisk", C.c_double), ("SofteningBulge", C.c_double),
+                ("SofteningStars", C.c_double), ("SofteningBndry", C.c_double),
+                ("SofteningGasMaxPhys", C.c_double), ("SofteningHaloMaxPhys", C.c_double),
+                ("SofteningDiskMaxPhys", C.c_double), ("SofteningBulgeMaxPhys", C.c_double),
+                ("SofteningStarsMaxPhys", C.c_double), ("SofteningBndryMaxPhys", C.c_double),
+                ("SofteningTable", C.c_double * 6), ("ForceSoftening", C.c_double * 6),
+                ("Rcut", C.c_double * 2), ("Asmth", C.c_double * 2),
+                ("TotNumOfForces", C.c_longlong), ("BunchSize", C.c_int),
+                ("BufferSize", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("periodic", C.c_int), ("pmgrid", C.c_int), ("unequal_softenings", C.c_int),
+                ("device", C.c_int)]
+
+
+ENDRUN_CB = C.CFUNCTYPE(None, C.c_int)
+
+EXPORTS = ["gadget_force_init", "gadget_force_finalize", "gadget_force_last_error",
+           "gadget_force_ctx", "gadget_force_layout", "gadget_force_set_endrun",
+           "gadget_force_mark_dirty", "endrun", "set_softenings", "domain_findExtent",
+           "force_treebuild", "ewald_init", "gravity_tree", "density", "density_isactive",
+           "force_update_hmax", "hydro_force", "force_treeevaluate",
+           "force_treeevaluate_shortrange", "force_treeevaluate_ewald_correction",
+           "density_evaluate", "hydro_evaluate", "ngb_treefind_variable", "ngb_treefind_pairs",
+           "peano_hilbert_key", "morton_key", "hubble_function",
+           "P", "SphP", "All", "NumPart", "N_gas", "FirstActiveParticle", "NextActiveParticle",
+           "TreeReconstructFlag", "DomainCorner", "DomainCenter", "DomainLen", "DomainFac",
+           "Ngblist", "GravDataGet", "GravDataResult"]
+
+_LIB = None
+
+
+def lib_path():
+    if not os.path.exists(_pkg.LIBHOST):
+        raise RuntimeError("libgadget_force.so is missing (%s): run __graft_entry__.build()"
+                           % _pkg.LIBHOST)
+    return _pkg.LIBHOST
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _pkg.lib_path()  # libghip.so must exist too
+        L = C.CDLL(lib_path(), mode=C.RTLD_GLOBAL)
+        L.gadget_force_init.argtypes = [C.POINTER(Config)]
+        L.gadget_force_last_error.restype = C.c_char_p
+        L.gadget_force_ctx.restype = C.c_void_p
+        L.gadget_force_set_endrun.argtypes = [ENDRUN_CB]
+        for f in ("force_treeevaluate", "force_treeevaluate_shortrange",
+                  "force_treeevaluate_ewald_correction", "density_evaluate", "hydro_evaluate"):
+            getattr(L, f).argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for f in ("ngb_treefind_variable", "ngb_treefind_pairs"):
+            getattr(L, f).argtypes = [C.POINTER(C.c_double), C.c_double, C.c_int,
+                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+        L.force_treebuild.argtypes = [C.c_int, C.c_void_p]
+        L.density_isactive.argtypes = [C.c_int]
+        L.peano_hilbert_key.argtypes = [C.c_int] * 4
+        L.peano_hilbert_key.restype = C.c_ulonglong
+        L.morton_key.argtypes = [C.c_int] * 4
+        L.morton_key.restype = C.c_ulonglong
+        L.hubble_function.argtypes = [C.c_double]
+        L.hubble_function.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+class Host:
+    """Owns the numpy arrays standing in for the reference's P[], SphP[], NextActiveParticle[]
+    and points the library's globals at them."""
+
+    def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0):
+        self.L = lib()
+        self.endrun_codes = []
+        self._cb = ENDRUN_CB(lambda code: self.endrun_codes.append(code))
+        self.L.gadget_force_set_endrun(self._cb)
+        cfg = Config(periodic, pmgrid, unequal, device)
+        rc = self.L.gadget_force_init(C.byref(cfg))
+        if rc != 0:
+            raise RuntimeError("gadget_force_init failed (%d): %s" %
+                               (rc, self.L.gadget_force_last_error().decode()))
+        self.All = AllStruct.in_dll(self.L, "All")
+
+    def close(self):
+        self.L.gadget_force_finalize()
+
+    def _setp(self, name, arr):
+        C.c_void_p.in_dll(self.L, name).value = arr.ctypes.data if arr is not None else None
+
+    def _seti(self, name, v):
+        C.c_int.in_dll(self.L, name).value = int(v)
+
+    def _geti(self, name):
+        return C.c_int.in_dll(self.L, name).value
+
+    def set_particles(self, P, SphP):
+        assert P.dtype == P_DTYPE and (SphP is None or SphP.dtype == SPH_DTYPE)
+        self.P, self.SphP = P, SphP
+        self._setp("P", P)
+        self._setp("SphP", SphP)
+        self._seti("NumPart", len(P))
+        self._seti("N_gas", 0 if SphP is None else len(SphP))
+        self.All.MaxPart = len(P)
+        self.L.gadget_force_mark_dirty()
+        self._seti("TreeReconstructFlag", 1)
+
+    def set_active(self, idx=None):
+        """Thread FirstActiveParticle/NextActiveParticle like run.c:300-320."""
+        n = len(self.P)
+        nxt = np.full(n, -1, np.int32)
+        idx = np.arange(n, dtype=np.int32) if idx is None else np.asarray(idx, np.int32)
+        if len(idx):
+            nxt[idx[:-1]] = idx[1:]
+            first = int(idx[0])
+        else:
+            first = -1
+        self.next_active = nxt
+        self._setp("NextActiveParticle", nxt)
+        self._seti("FirstActiveParticle", first)
+
+    def domain(self):
+        self.L.domain_findExtent()
+        d3 = C.c_double * 3
+        return (np.array(d3.in_dll(self.L, "DomainCorner")),
+                np.array(d3.in_dll(self.L, "DomainCenter")),
+                C.c_double.in_dll(self.L, "DomainLen").value)
+
+    def ngblist(self, count):
+        ptr = C.POINTER(C.c_int).in_dll(self.L, "Ngblist")
+        return np.array([ptr[i] for i in range(count)], np.int32)

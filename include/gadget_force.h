@@ -1,0 +1,228 @@
+/*
+ * gadget_force.h -- host-side mirror of the reference's call surface for the force path.
+ *
+ * The reference host is plain C on global AoS arrays (allvars.h, proto.h, forcetree.h).  This
+ * header restates exactly the part of that interface the force path touches, with the same
+ * names, argument meaning and error behaviour, so that
+ *   (a) accel.c (accel.c:27-313) can call gravity_tree() / density() / force_update_hmax() /
+ *       hydro_force() unchanged, and
+ *   (b) the parity tests read like tests of the reference's own functions.
+ * Everything computes on the GPU through include/ghip.h; there is no CPU fallback.
+ *
+ * Struct layout: the MINIMAL periodic flag set of BASELINE.md (-DPERIODIC -DPEANOHILBERT
+ * -DDOUBLEPRECISION ...: sizeof(particle_data) = 112, sizeof(sph_particle_data) = 184,
+ * SURVEY.md 8b).  A host built with another -D set keeps its own allvars.h and passes its own
+ * offsets through ghip_layout; nothing in libghip.so depends on this struct.
+ *
+ * Reference interfaces replaced (file:line):
+ *   gravity_tree            gravtree.c:27        set_softenings        gravtree.c:835
+ *   force_treebuild         forcetree.c:67       force_update_hmax     forcetree.c:1661
+ *   force_treeevaluate      forcetree.c:1797     ..._shortrange        forcetree.c:2330
+ *   ..._ewald_correction    forcetree.c:2873     ewald_init            forcetree.c:4402
+ *   density                 density.c:89         density_evaluate      density.c:711
+ *   density_isactive        density.c:1035       hydro_force           hydra.c:145
+ *   hydro_evaluate          hydra.c:822          ngb_treefind_variable ngb.c:169
+ *   ngb_treefind_pairs      ngb.c:32             peano_hilbert_key     peano.c:300
+ *   morton_key              peano.c:320          domain_findExtent     domain.c:1972
+ *   endrun                  endrun.c:23
+ */
+#ifndef GADGET_FORCE_H
+#define GADGET_FORCE_H
+
+#include "ghip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double MyFloat;       /* DOUBLEPRECISION, allvars.h:154-165 */
+typedef double MyDouble;
+typedef double MyLongDouble;  /* no FLTROUNDOFFREDUCTION, allvars.h:191-202 */
+typedef unsigned long long peanokey; /* allvars.h:55 */
+
+#define BITS_PER_DIMENSION 21 /* allvars.h:58 */
+#define NODELISTLENGTH 8
+#define GAMMA (7. / 5.)       /* allvars.h:64 */
+#define GAMMA_MINUS1 (GAMMA - 1)
+
+/* allvars.h:1131-1377, minimal flag set: 112 bytes */
+struct particle_data
+{
+  MyDouble Pos[3];
+  MyDouble Vel[3];
+  MyDouble Mass;
+  unsigned int ID;
+  union
+  {
+    MyFloat GravAccel[3];
+    MyLongDouble dGravAccel[3];
+  } g;
+  MyFloat OldAcc;
+  float GravCost;
+  int Ti_begstep;
+  int Ti_current;
+  short int Type;
+  short int TimeBin;
+};
+
+/* allvars.h:1384-1639, minimal flag set (+BH_THERMALFEEDBACK's `i`): 184 bytes */
+struct sph_particle_data
+{
+  MyDouble Entropy;
+  MyFloat Pressure;
+  MyDouble VelPred[3];
+  MyFloat MaxSignalVel;
+  union
+  {
+    MyFloat Density;
+    MyLongDouble dDensity;
+  } d;
+  union
+  {
+    MyFloat DtEntropy;
+    MyLongDouble dDtEntropy;
+  } e;
+  union
+  {
+    MyFloat HydroAccel[3];
+    MyLongDouble dHydroAccel[3];
+  } a;
+  union
+  {
+    MyFloat DhsmlDensityFactor;
+    MyLongDouble dDhsmlDensityFactor;
+  } h;
+  union
+  {
+    MyFloat DivVel;
+    MyLongDouble dDivVel;
+  } v;
+  union
+  {
+    MyFloat CurlVel;
+    MyFloat Rot[3];
+    MyLongDouble dRot[3];
+  } r;
+  MyFloat Hsml;   /* PPP == SphP when !BLACK_HOLES && !DUST, allvars.h:266-270 */
+  MyFloat Left, Right;
+  union
+  {
+    MyFloat NumNgb;
+    MyLongDouble dNumNgb;
+  } n;
+  union
+  {
+    MyFloat Injected_BH_Energy;
+    MyLongDouble dInjected_BH_Energy;
+  } i;
+  MyFloat pad_[2];
+};
+
+#define PPP SphP /* allvars.h:266-270 */
+
+/* the members of `All` (struct global_data_all_processes, allvars.h:530-1123) the path uses */
+struct global_data_all_processes
+{
+  int MaxPart;
+  double G;
+  double ErrTolTheta, ErrTolForceAcc;
+  int TypeOfOpeningCriterion;
+  double BoxSize;
+  double DesNumNgb, MaxNumNgbDeviation;
+  double MinGasHsmlFractional, MinGasHsml;
+  double ArtBulkViscConst;
+  int Ti_Current;
+  double Timebase_interval;
+  double Time;
+  int ComovingIntegrationOn;
+  double Hubble, Omega0, OmegaLambda; /* hubble_function(), darkenergy.c:389 (no DARKENERGY) */
+  double SofteningGas, SofteningHalo, SofteningDisk, SofteningBulge, SofteningStars, SofteningBndry;
+  double SofteningGasMaxPhys, SofteningHaloMaxPhys, SofteningDiskMaxPhys, SofteningBulgeMaxPhys,
+    SofteningStarsMaxPhys, SofteningBndryMaxPhys;
+  double SofteningTable[6], ForceSoftening[6];
+  double Rcut[2], Asmth[2];           /* PMGRID */
+  long long TotNumOfForces;
+  int BunchSize;
+  double BufferSize;
+};
+
+/* gravdata_in / gravdata_out, allvars.h:1690-1716 (mode == 1 records) */
+struct gravdata_in
+{
+  MyFloat Pos[3];
+  int Type;
+  MyFloat OldAcc;
+  int NodeList[NODELISTLENGTH];
+};
+struct gravdata_out
+{
+  MyLongDouble Acc[3];
+  int Ninteractions;
+};
+
+/* compile-time switches of the reference that this library takes at run time */
+struct gadget_force_config
+{
+  int periodic;            /* -DPERIODIC */
+  int pmgrid;              /* -DPMGRID=n (0: off): gravity_tree uses the short-range walk */
+  int unequal_softenings;  /* -DUNEQUALSOFTENINGS */
+  int device;              /* GPU ordinal of this rank */
+};
+
+/* ---- globals with the reference's names (allvars.c) ---- */
+extern struct particle_data *P;
+extern struct sph_particle_data *SphP;
+extern struct global_data_all_processes All;
+extern int NumPart, N_gas;
+extern int FirstActiveParticle, *NextActiveParticle;
+extern int TreeReconstructFlag;
+extern double DomainCorner[3], DomainCenter[3], DomainLen, DomainFac;
+extern int *Ngblist;
+extern struct gravdata_in *GravDataGet;
+extern struct gravdata_out *GravDataResult;
+extern int ThisTask, NTask;
+extern double CPU_Step_Treewalk, CPU_Step_Treebuild, CPU_Step_Density, CPU_Step_Hydro,
+  CPU_Step_Hmaxupdate; /* the CPU_Step[] buckets the path fills (allvars.h:205-238) */
+
+/* ---- library management (no counterpart in the reference) ---- */
+int gadget_force_init(const struct gadget_force_config *cfg);  /* 0 or a GHIP_E* code */
+void gadget_force_finalize(void);
+const char *gadget_force_last_error(void);
+ghip_ctx *gadget_force_ctx(void);
+void gadget_force_layout(ghip_layout *lay);   /* offsets of the structs above */
+/* endrun(code) handler: default prints "task %d: endrun called with an error level of %d" and
+ * abort()s like MPI_Abort would; tests install a recording handler. */
+void gadget_force_set_endrun(void (*handler)(int code));
+/* tell the glue that the host changed P/SphP outside the four drivers */
+void gadget_force_mark_dirty(void);
+
+/* ---- the reference's call surface ---- */
+void endrun(int ierr);
+void set_softenings(void);
+void domain_findExtent(void);
+int force_treebuild(int npart, void *mp);
+void ewald_init(void);
+void gravity_tree(void);
+void density(void);
+int density_isactive(int n);
+void force_update_hmax(void);
+void hydro_force(void);
+
+int force_treeevaluate(int target, int mode, int *nexport, int *nsend_local);
+int force_treeevaluate_shortrange(int target, int mode, int *nexport, int *nsend_local);
+int force_treeevaluate_ewald_correction(int target, int mode, int *nexport, int *nsend_local);
+int density_evaluate(int target, int mode, int *nexport, int *nsend_local);
+int hydro_evaluate(int target, int mode, int *nexport, int *nsend_local);
+int ngb_treefind_variable(MyDouble searchcenter[3], MyFloat hsml, int target, int *startnode,
+                          int mode, int *nexport, int *nsend_local);
+int ngb_treefind_pairs(MyDouble searchcenter[3], MyFloat hsml, int target, int *startnode,
+                       int mode, int *nexport, int *nsend_local);
+
+peanokey peano_hilbert_key(int x, int y, int z, int bits);
+peanokey morton_key(int x, int y, int z, int bits);
+double hubble_function(double a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -114,6 +114,8 @@ typedef struct
   int ComovingIntegrationOn;
   double hubble_a2, fac_mu, fac_vsic_fix; /* hydra.c:192-208 (1 when not comoving) */
   double Timebase_interval;
+  int raw_dtentropy;         /* 1: leave DtEntropy as hydro_evaluate's raw sum (hydra.c:1934), skip
+                              * hydro_force's conversion to dA/dt (hydra.c:583) */
 } ghip_hydro_params;
 
 /* work counters of the last phase, counted exactly as the reference counts them
@@ -131,6 +133,8 @@ typedef struct
   int tree_nodes, gastree_nodes;
   /* device time of the last call of each phase, ms, measured with hipEvents on the ctx stream */
   float ms_tree, ms_grav, ms_ewald, ms_dens, ms_hmax, ms_hydro;
+  /* walk efficiency: elements visited summed over wavefronts (64 targets share each visit) */
+  long long grav_wave_steps, ewald_wave_steps;
 } ghip_stats;
 
 /* ---- lifetime ---- */

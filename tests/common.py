@@ -99,7 +99,7 @@ class Problem:
     def g_hydro(self, comoving=0, hubble_a2=1.0, fac_mu=1.0, fac_vsic_fix=1.0):
         B = bindings()
         return B.HydroParams(self.visc, self.box, self.periodic, comoving, hubble_a2, fac_mu,
-                             fac_vsic_fix, self.timebase)
+                             fac_vsic_fix, self.timebase, 0)
 
     # ---- oracle side ----
     def oracle_tree(self, hsml=None, toplevels=0):

@@ -1,0 +1,162 @@
+"""CPU-side checks of the boundary: the C-ABI libraries load and export every symbol the
+headers declare, struct layouts match the reference's, host-side helpers agree
+with the oracle, and the product fails loudly -- never falls back to a CPU path -- without a GPU.
+No compute entry point is called here.
+"""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import O, REPO, Problem, bindings, pkg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _declared_functions(header):
+    src = open(os.path.join(REPO, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_libghip_exports_every_declared_symbol():
+    L = C.CDLL(pkg.lib_path())
+    decl = _declared_functions("ghip.h")
+    assert len(decl) >= 30
+    for name in decl:
+        assert hasattr(L, name), "libghip.so does not export %s" % name
+    B = bindings()
+    assert set(B.EXPORTS) <= set(decl)
+    assert B.lib().ghip_version().startswith(b"ghip")
+
+
+def test_libgadget_force_exports_the_reference_call_surface():
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    L = H.lib()
+    for name in _declared_functions("gadget_force.h"):
+        assert hasattr(L, name), "libgadget_force.so does not export %s" % name
+    for name in H.EXPORTS:
+        assert hasattr(L, name), name
+    # the four void(void) symbols accel.c links against (accel.c:61, 84, 96, 106)
+    for name in ("gravity_tree", "density", "force_update_hmax", "hydro_force"):
+        assert hasattr(L, name)
+
+
+def test_struct_layouts_match_the_reference_minimal_flag_set():
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    B = bindings()
+    assert H.P_DTYPE.itemsize == 112 and H.SPH_DTYPE.itemsize == 184
+    lay = B.Layout()
+    H.lib().gadget_force_layout(C.byref(lay))
+    want_p = dict(p_stride=112, p_pos=0, p_vel=24, p_mass=48, p_gravaccel=64, p_oldacc=88,
+                  p_gravcost=96, p_ti_begstep=100, p_type=108, p_timebin=110, p_hsml=-1,
+                  p_numngb=-1)
+    want_s = dict(s_stride=184, s_entropy=0, s_pressure=8, s_velpred=16, s_maxsignalvel=40,
+                  s_density=48, s_dtentropy=56, s_hydroaccel=64, s_dhsmlfac=88, s_divvel=96,
+                  s_curlvel=104)
+    for k, v in {**want_p, **want_s}.items():
+        assert getattr(lay, k) == v, k
+    assert lay.s_hsml == H.SPH_DTYPE.fields["Hsml"][1]
+    assert lay.s_numngb == H.SPH_DTYPE.fields["NumNgb"][1]
+    for name, off in (("Pos", 0), ("Mass", 48), ("GravAccel", 64), ("Type", 108)):
+        assert H.P_DTYPE.fields[name][1] == off
+
+
+def test_host_key_functions_match_golden_vectors_and_oracle():
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    L = H.lib()
+    g = np.load(os.path.join(GOLD, "peano_keys.npz"))
+    for bits, (x, y, z), ph, mo in zip(g["bits"], g["xyz"], g["peano"], g["morton"]):
+        assert L.peano_hilbert_key(int(x), int(y), int(z), int(bits)) == int(ph)
+        assert L.morton_key(int(x), int(y), int(z), int(bits)) == int(mo)
+    rng = np.random.default_rng(5)
+    for x, y, z in rng.integers(0, 1 << 21, size=(200, 3)):
+        assert L.peano_hilbert_key(int(x), int(y), int(z), 21) == O.peano_hilbert_key(x, y, z, 21)
+
+
+def test_set_softenings_and_hubble_function():
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    L = H.lib()
+    All = H.AllStruct.in_dll(L, "All")
+    All.ComovingIntegrationOn = 1
+    All.Time = 0.5
+    vals = (0.01, 0.02, 0.03, 0.04, 0.05, 0.06)
+    for name, v in zip(("Gas", "Halo", "Disk", "Bulge", "Stars", "Bndry"), vals):
+        setattr(All, "Softening" + name, v)
+        setattr(All, "Softening" + name + "MaxPhys", 0.012)
+    All.MinGasHsmlFractional = 0.25
+    L.set_softenings()
+    # gravtree.c:839-868: comoving softening capped at MaxPhys / a
+    want = [v if v * 0.5 <= 0.012 else 0.012 / 0.5 for v in vals]
+    assert np.allclose(list(All.SofteningTable), want)
+    assert np.allclose(list(All.ForceSoftening), 2.8 * np.array(want))
+    assert np.isclose(All.MinGasHsml, 0.25 * 2.8 * want[0])
+    All.ComovingIntegrationOn = 0
+    L.set_softenings()
+    assert np.allclose(list(All.SofteningTable), vals)
+    All.Hubble, All.Omega0, All.OmegaLambda = 0.1, 0.3, 0.7
+    assert np.isclose(L.hubble_function(1.0), 0.1)
+    assert np.isclose(L.hubble_function(0.5), 0.1 * np.sqrt(0.3 / 0.125 + 0.7))
+
+
+def test_domain_find_extent_matches_oracle():
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    L = H.lib()
+    pr = Problem(ng=6, gas=True)
+    P = np.zeros(pr.n, H.P_DTYPE)
+    P["Pos"] = pr.ic["pos"]
+    C.c_void_p.in_dll(L, "P").value = P.ctypes.data
+    C.c_int.in_dll(L, "NumPart").value = pr.n
+    L.domain_findExtent()
+    d3 = C.c_double * 3
+    corner, center, ln = pr.extent
+    assert np.array_equal(np.array(d3.in_dll(L, "DomainCorner")), corner)
+    assert np.array_equal(np.array(d3.in_dll(L, "DomainCenter")), center)
+    assert C.c_double.in_dll(L, "DomainLen").value == ln
+    assert C.c_double.in_dll(L, "DomainFac").value == 1.0 / ln * (1 << 21)
+    C.c_void_p.in_dll(L, "P").value = None
+    C.c_int.in_dll(L, "NumPart").value = 0
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_a_gpu():
+    B = bindings()
+    with pytest.raises(B.GhipError) as ei:
+        B.ForcePath(0)
+    assert ei.value.code == -90005 and "no CPU path" in str(ei.value)
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    with pytest.raises(RuntimeError) as ei:
+        H.Host()
+    assert "no CPU path" in str(ei.value)
+    # and the drivers refuse to run (endrun, endrun.c:23) instead of computing on the host
+    codes = []
+    cb = H.ENDRUN_CB(lambda c: codes.append(c))
+    H.lib().gadget_force_set_endrun(cb)
+    H.lib().gravity_tree()
+    H.lib().density()
+    H.lib().hydro_force()
+    assert codes == [90005, 90005, 90005]
+    H.lib().gadget_force_set_endrun(H.ENDRUN_CB(0))
+
+
+def test_product_package_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for root, _, files in os.walk(pkg.PKG_DIR):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                txt = open(os.path.join(root, f)).read()
+                for needle in ("import oracle", "from oracle", "libgadget_oracle", "orc_",
+                               "gadget_oracle.h"):
+                    assert needle not in txt, (root, f, needle)
