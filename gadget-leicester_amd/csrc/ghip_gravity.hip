@@ -1,320 +1,12 @@
-// ghip_gravity.hip -- Barnes-Hut tree-walk gravity on gfx950.
+// ghip_gravity.hip -- host drivers of the tree-walk gravity on gfx950 (kernels: ghip_walk.h).
 //
 // Replaces the active-list loop of gravity_tree() (gravtree.c:130-168) over
 // force_treeevaluate() (forcetree.c:1797-2317), force_treeevaluate_shortrange()
-// (forcetree.c:2330-2845) and force_treeevaluate_ewald_correction() (forcetree.c:2873-3204).
-//
-// One wavefront (64 lanes) walks the pre-order element list for a bucket of 64 targets that are
-// consecutive along the space-filling curve.  The element index is wave-uniform, so node and
-// particle records arrive through the scalar cache (s_load) and are broadcast for free; every
-// lane applies the reference's PER-PARTICLE opening criterion to the same node:
-//   * a lane that accepts the node interacts with its monopole and remembers the node's skip
-//     index -- it ignores every element below the node (my_skip);
-//   * the wave descends (e+1) if ANY participating lane must open, else jumps to the skip index.
-// Each lane therefore sees exactly the interaction set, in exactly the depth-first order, of the
-// reference's serial walk for its particle: parity is summation-identical, not merely within a
-// group-MAC bound.  No MFMA: this is irregular fp64 pairwise work.
+// (forcetree.c:2330-2845) and force_treeevaluate_ewald_correction() (forcetree.c:2873-3204),
+// the OldAcc / G post-pass (gravtree.c:381-403) and ewald_init() (forcetree.c:4402-4527).
 #include <cmath>
 
-#include "ghip_internal.h"
-
-struct GravK
-{
-  double theta2;       // ErrTolTheta^2 (0: relative criterion)
-  double errtol;       // ErrTolForceAcc
-  double boxsize, boxhalf;
-  int periodic, unequal;
-  int debug_steps;     // GHIP_DEBUG_STEPS=1: GRAVCOST receives the wave's visited-element count
-  double rcut, rcut2, asmthfac;  // shortrange
-  double fac_intp;     // ewald: 2*EN/BoxSize
-};
-
-// softened monopole kernel, forcetree.c:2143-2171
-__device__ __forceinline__ double d_grav_fac(double mass, double r2, double r, double h)
-{
-  if(r >= h)
-    return mass / (r2 * r);
-  double h_inv = 1.0 / h;
-  double h3_inv = h_inv * h_inv * h_inv;
-  double u = r * h_inv;
-  if(u < 0.5)
-    return mass * h3_inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
-  return mass * h3_inv *
-         (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
-          0.066666666667 / (u * u * u));
-}
-
-// trilinear Ewald look-up, forcetree.c:3097-3170.  tab: double4 (fx,fy,fz,0) per grid point.
-__device__ __forceinline__ void d_ewald_interp(const double4 *__restrict__ tab, double fac_intp,
-                                               double dx, double dy, double dz, double &fx,
-                                               double &fy, double &fz)
-{
-  const int E1 = GHIP_EN + 1;
-  double sx = -1, sy = -1, sz = -1;
-  if(dx < 0)
-    {
-      dx = -dx;
-      sx = +1;
-    }
-  if(dy < 0)
-    {
-      dy = -dy;
-      sy = +1;
-    }
-  if(dz < 0)
-    {
-      dz = -dz;
-      sz = +1;
-    }
-  double u = dx * fac_intp;
-  int i = (int) u;
-  if(i >= GHIP_EN)
-    i = GHIP_EN - 1;
-  u -= i;
-  double v = dy * fac_intp;
-  int j = (int) v;
-  if(j >= GHIP_EN)
-    j = GHIP_EN - 1;
-  v -= j;
-  double w = dz * fac_intp;
-  int k = (int) w;
-  if(k >= GHIP_EN)
-    k = GHIP_EN - 1;
-  w -= k;
-  double f1 = (1 - u) * (1 - v) * (1 - w), f2 = (1 - u) * (1 - v) * (w);
-  double f3 = (1 - u) * (v) * (1 - w), f4 = (1 - u) * (v) * (w);
-  double f5 = (u) * (1 - v) * (1 - w), f6 = (u) * (1 - v) * (w);
-  double f7 = (u) * (v) * (1 - w), f8 = (u) * (v) * (w);
-  const double4 *b = tab + ((size_t) i * E1 + j) * E1 + k;
-  double4 t1 = b[0], t2 = b[1], t3 = b[E1], t4 = b[E1 + 1];
-  double4 t5 = b[E1 * E1], t6 = b[E1 * E1 + 1], t7 = b[E1 * E1 + E1], t8 = b[E1 * E1 + E1 + 1];
-  fx = sx * (t1.x * f1 + t2.x * f2 + t3.x * f3 + t4.x * f4 + t5.x * f5 + t6.x * f6 + t7.x * f7 +
-             t8.x * f8);
-  fy = sy * (t1.y * f1 + t2.y * f2 + t3.y * f3 + t4.y * f4 + t5.y * f5 + t6.y * f6 + t7.y * f7 +
-             t8.y * f8);
-  fz = sz * (t1.z * f1 + t2.z * f2 + t3.z * f3 + t4.z * f4 + t5.z * f5 + t6.z * f6 + t7.z * f7 +
-             t8.z * f8);
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(GHIP_BLOCK)
-k_grav_walk(int nelem, const double4 *__restrict__ xm, const double4 *__restrict__ cl,
-            const int4 *__restrict__ lk, const double *__restrict__ aux, int nt,
-            const int *__restrict__ tgt, const double *__restrict__ tx,
-            const double *__restrict__ ty, const double *__restrict__ tz,
-            const double *__restrict__ tsoft, const double *__restrict__ toldacc, GravK p,
-            const float *__restrict__ srtab, const double4 *__restrict__ ewtab,
-            double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
-            int *__restrict__ cost, unsigned long long *__restrict__ counter)
-{
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int ti = wave * 64 + lane;
-  const bool valid = ti < nt;
-  const int s = valid ? (tgt ? tgt[ti] : ti) : 0;
-
-  double pos_x = 0, pos_y = 0, pos_z = 0, h_i = 1, aold = 0;
-  if(valid)
-    {
-      pos_x = tx[s];
-      pos_y = ty[s];
-      pos_z = tz[s];
-      h_i = tsoft[s];
-      aold = p.errtol * toldacc[s];
-    }
-  double acc_x = 0, acc_y = 0, acc_z = 0;
-  int nint = 0;
-  int my_skip = valid ? 0 : 0x7fffffff;
-  unsigned int steps = 0;
-
-  int e = 0;
-  while(e < nelem)
-    {
-      e = __builtin_amdgcn_readfirstlane(e);
-      steps++;
-      const double4 v = xm[e];
-      const int4 k = lk[e];
-      const bool act = (e >= my_skip);
-      int next;
-
-      double dx = v.x - pos_x, dy = v.y - pos_y, dz = v.z - pos_z;
-      if(MODE == GHIP_WALK_EWALD || p.periodic)
-        {
-          dx = d_nearest(dx, p.boxsize, p.boxhalf);
-          dy = d_nearest(dy, p.boxsize, p.boxhalf);
-          dz = d_nearest(dz, p.boxsize, p.boxhalf);
-        }
-      const double r2 = dx * dx + dy * dy + dz * dz;
-      const double mass = v.w;
-      double h = h_i;
-      bool interact = act;
-
-      if(LK_IS_PARTICLE(k))
-        {
-          next = e + 1;
-          if(MODE != GHIP_WALK_EWALD && p.unequal)
-            {
-              double sj = aux[e];
-              if(h < sj)
-                h = sj;
-            }
-        }
-      else
-        {
-          const double4 c = cl[e];
-          const double len = c.w;
-          bool open = false;
-          if(act)
-            {
-              if(MODE == GHIP_WALK_SHORTRANGE)
-                {
-                  // forcetree.c:2598-2632: whole cell beyond the cut-off -> drop the branch
-                  if(r2 > p.rcut2)
-                    {
-                      double eff = p.rcut + 0.5 * len;
-                      double d0 = c.x - pos_x, d1 = c.y - pos_y, d2 = c.z - pos_z;
-                      if(p.periodic)
-                        {
-                          d0 = d_nearest(d0, p.boxsize, p.boxhalf);
-                          d1 = d_nearest(d1, p.boxsize, p.boxhalf);
-                          d2 = d_nearest(d2, p.boxsize, p.boxhalf);
-                        }
-                      if(d0 < -eff || d0 > eff || d1 < -eff || d1 > eff || d2 < -eff || d2 > eff)
-                        {
-                          interact = false;
-                          my_skip = k.x;
-                        }
-                    }
-                }
-              if(interact)
-                {
-                  // opening criterion, forcetree.c:2074-2105
-                  if(p.theta2 != 0)
-                    open = (len * len > r2 * p.theta2);
-                  else
-                    {
-                      open = (mass * len * len > r2 * r2 * aold);
-                      if(!open)
-                        open = (fabs(c.x - pos_x) < 0.60 * len) && (fabs(c.y - pos_y) < 0.60 * len) &&
-                               (fabs(c.z - pos_z) < 0.60 * len);
-                    }
-                  if(MODE == GHIP_WALK_EWALD)
-                    {
-                      // forcetree.c:3039-3088: the correction is smooth, so an "open" verdict is
-                      // overridden unless the cell straddles the half-box or is large
-                      if(open)
-                        {
-                          bool must = false;
-                          double u0 = d_nearest(c.x - pos_x, p.boxsize, p.boxhalf);
-                          double u1 = d_nearest(c.y - pos_y, p.boxsize, p.boxhalf);
-                          double u2 = d_nearest(c.z - pos_z, p.boxsize, p.boxhalf);
-                          double lim = 0.5 * (p.boxsize - len);
-                          must = (fabs(u0) > lim) || (fabs(u1) > lim) || (fabs(u2) > lim) ||
-                                 (len > 0.20 * p.boxsize);
-                          open = must;
-                        }
-                    }
-                  else if(p.unequal && !open)
-                    {
-                      // forcetree.c:2108-2124
-                      double a = aux[e];
-                      double ms = fabs(a);
-                      if(h < ms)
-                        {
-                          h = ms;
-                          if(r2 < h * h && a < 0)
-                            open = true;
-                        }
-                    }
-                  if(open)
-                    interact = false;
-                  else
-                    my_skip = k.x;
-                }
-            }
-          next = __any(open) ? e + 1 : k.x;
-        }
-
-      if(interact)
-        {
-          if(MODE == GHIP_WALK_EWALD)
-            {
-              double fx, fy, fz;
-              d_ewald_interp(ewtab, p.fac_intp, dx, dy, dz, fx, fy, fz);
-              acc_x += mass * fx;
-              acc_y += mass * fy;
-              acc_z += mass * fz;
-              nint++;
-            }
-          else
-            {
-              const double r = sqrt(r2);
-              double fac = d_grav_fac(mass, r2, r, h);
-              if(MODE == GHIP_WALK_SHORTRANGE)
-                {
-                  // forcetree.c:2739-2752
-                  int tabindex = (int) (p.asmthfac * r);
-                  if(tabindex < GHIP_NTAB)
-                    {
-                      fac *= srtab[tabindex];
-                      acc_x += dx * fac;
-                      acc_y += dy * fac;
-                      acc_z += dz * fac;
-                      nint++;
-                    }
-                }
-              else
-                {
-                  acc_x += dx * fac;
-                  acc_y += dy * fac;
-                  acc_z += dz * fac;
-                  if(mass > 0)
-                    nint++;
-                }
-            }
-        }
-      e = next;
-    }
-
-  if(valid)
-    {
-      ax[ti] = acc_x;
-      ay[ti] = acc_y;
-      az[ti] = acc_z;
-      cost[ti] = p.debug_steps ? (int) steps : nint;
-    }
-  unsigned long long tot = d_wave_sum_u64((unsigned long long) nint);
-  if(lane == 0 && tot)
-    atomicAdd(counter, tot);
-  if(lane == 0)
-    atomicAdd(counter + 8, (unsigned long long) steps);
-}
-
-// results from target order to host order; EWALD adds (forcetree.c:3190-3193)
-__global__ void k_scatter_grav(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
-                               const double *__restrict__ ax, const double *__restrict__ ay,
-                               const double *__restrict__ az, const int *__restrict__ cost, int n,
-                               double *__restrict__ oacc, int *__restrict__ ocost, int accumulate)
-{
-  int ti = blockIdx.x * blockDim.x + threadIdx.x;
-  if(ti >= nt)
-    return;
-  int i = perm[tgt[ti]];
-  if(accumulate)
-    {
-      oacc[i] += ax[ti];
-      oacc[(size_t) n + i] += ay[ti];
-      oacc[2 * (size_t) n + i] += az[ti];
-      ocost[i] += cost[ti];
-    }
-  else
-    {
-      oacc[i] = ax[ti];
-      oacc[(size_t) n + i] = ay[ti];
-      oacc[2 * (size_t) n + i] = az[ti];
-      ocost[i] = cost[ti];
-    }
-}
+#include "ghip_walk.h"
 
 // gravtree.c:381-403: OldAcc = |GravAccel| (G-less), then GravAccel *= G
 __global__ void k_grav_finish(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
@@ -376,8 +68,8 @@ k_grav_direct(int n, const double *__restrict__ sx, const double *__restrict__ s
           double h = hi;
           if(p.unequal && h < ls[q])
             h = ls[q];
-          double r = sqrt(r2);
-          double fac = d_grav_fac(lm[q], r2, r, h);
+          double r;
+          double fac = d_grav_fac(lm[q], r2, h, h * h, r);
           a0 += dx * fac;
           a1 += dy * fac;
           a2 += dz * fac;
@@ -485,7 +177,7 @@ extern "C" int ghip_ewald_get_table(ghip_ctx *ctx, double *host)
 
 static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, GravK &k)
 {
-  k.theta2 = p->ErrTolTheta * p->ErrTolTheta;
+  k.theta = p->ErrTolTheta;
   k.errtol = p->ErrTolForceAcc;
   k.boxsize = p->BoxSize;
   k.boxhalf = 0.5 * p->BoxSize;
@@ -526,16 +218,95 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   return GHIP_OK;
 }
 
-template <int MODE>
-static void launch_walk(ghip_ctx *ctx, const TreeDev &t, int nt, const int *tgt, const double *tx,
-                        const double *ty, const double *tz, const double *tsoft,
-                        const double *toldacc, const GravK &k, unsigned long long *counter)
+// segment table of the gravity tree; called at the end of every tree build
+int ghip_build_segments(ghip_ctx *ctx, TreeDev &t)
 {
-  int blocks = cdiv(nt, GHIP_BLOCK);
-  k_grav_walk<MODE><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
-    t.nelem, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), nt, tgt, tx, ty,
-    tz, tsoft, toldacc, k, P<float>(ctx->srtab), P<double4>(ctx->ewtab), P<double>(ctx->tax),
-    P<double>(ctx->tay), P<double>(ctx->taz), P<int>(ctx->tcost), counter);
+  t.ns = 1;
+  if(t.n == 0)
+    return GHIP_OK;
+  int ns = t.nelem / 4096;      // >= 4096 elements per segment, at most 64 segments
+  if(ns < 1)
+    ns = 1;
+  if(ns > 64)
+    ns = 64;
+  if(getenv("GHIP_WALK_SEGMENTS"))
+    {
+      int v = atoi(getenv("GHIP_WALK_SEGMENTS"));
+      if(v >= 1 && v <= 4096)
+        ns = v;
+    }
+  t.ns = ns;
+  GCHK(ghip_ensure(ctx, t.seg_start, (size_t) (ns + 1) * 4));
+  GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) ns * 4));
+  GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) ns * GHIP_MAXANC * 4));
+  k_build_segments<<<cdiv(ns + 1, 64), 64, 0, ctx->stream>>>(
+    t.nelem, P<int4>(t.lk), ns, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
+  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkElem)));
+  k_fill_elems<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double4>(t.xm),
+                                                           P<double4>(t.cl), P<int4>(t.lk),
+                                                           P<double>(t.aux), P<WalkElem>(t.mq));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
+{
+  sg.ns = t.ns;
+  sg.nsub = t.ns < GHIP_MAXSUB ? t.ns : GHIP_MAXSUB;
+  if(sg.nsub < 1)
+    sg.nsub = 1;
+  sg.start = P<int>(t.seg_start);
+  sg.nanc = P<int>(t.seg_nanc);
+  sg.anc = P<int>(t.seg_anc);
+  *nbuckets = (nt + 63) / 64;
+  return sg.nsub;
+}
+
+static int ensure_partials(ghip_ctx *ctx, int nt, int nsub)
+{
+  size_t cnt = (size_t) nt * nsub;
+  GCHK(ghip_ensure(ctx, ctx->tax, cnt * 8));
+  GCHK(ghip_ensure(ctx, ctx->tay, cnt * 8));
+  GCHK(ghip_ensure(ctx, ctx->taz, cnt * 8));
+  GCHK(ghip_ensure(ctx, ctx->tcost, cnt * 4));
+  return GHIP_OK;
+}
+
+template <int MODE>
+static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int nbuckets, int nt,
+                        const int *tgt, const double *tx, const double *ty, const double *tz,
+                        const double *tsoft, const double *toldacc, const GravK &k,
+                        unsigned long long *counter)
+{
+  long long nthreads = (long long) nbuckets * sg.nsub * 64;
+  int blocks = cdiv(nthreads, GHIP_BLOCK);
+  blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
+  if(k.periodic)
+    k_grav_walk<MODE, true><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
+      t.nelem, P<WalkElem>(t.mq), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+      P<float>(ctx->srtab), P<double4>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
+      P<double>(ctx->taz), P<int>(ctx->tcost), counter);
+  else
+    k_grav_walk<MODE, false><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
+      t.nelem, P<WalkElem>(t.mq), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+      P<float>(ctx->srtab), P<double4>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
+      P<double>(ctx->taz), P<int>(ctx->tcost), counter);
+}
+
+static void launch_walk_any(ghip_ctx *ctx, int walk, const TreeDev &t, const WalkSeg &sg,
+                            int nbuckets, int nt, const int *tgt, const double *tx,
+                            const double *ty, const double *tz, const double *tsoft,
+                            const double *toldacc, const GravK &k, unsigned long long *counter)
+{
+  if(walk == GHIP_WALK_NEWTON)
+    launch_walk<GHIP_WALK_NEWTON>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+                                  counter);
+  else if(walk == GHIP_WALK_SHORTRANGE)
+    launch_walk<GHIP_WALK_SHORTRANGE>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+                                      counter);
+  else
+    launch_walk<GHIP_WALK_EWALD>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+                                 counter);
 }
 
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
@@ -575,13 +346,13 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   if(nt == 0 || n == 0)
     return GHIP_OK;
   const int *tgt = P<int>(ctx->tg_grav) + lo;
-
-  GCHK(ghip_ensure(ctx, ctx->tax, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tay, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->taz, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tcost, (size_t) nt * 4));
+  WalkSeg sg;
+  int nbuckets;
+  int nsub = walk_layout(ctx->gt, nt, sg, &nbuckets);
+  GCHK(ensure_partials(ctx, nt, nsub));
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
-  unsigned long long *counter = P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
+  unsigned long long *counter =
+    P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
   HIPCHK(hipMemsetAsync(counter + 8, 0, 8, st));
 
@@ -591,21 +362,16 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 
   int evi = (walk == GHIP_WALK_EWALD) ? 4 : 2;
   HIPCHK(hipEventRecord(ctx->ev[evi], st));
-  const double *tx = P<double>(ctx->sx), *ty = P<double>(ctx->sy), *tz = P<double>(ctx->sz);
-  const double *ts = P<double>(ctx->ssoft), *to = P<double>(ctx->soldacc);
-  if(walk == GHIP_WALK_NEWTON)
-    launch_walk<GHIP_WALK_NEWTON>(ctx, ctx->gt, nt, tgt, tx, ty, tz, ts, to, k, counter);
-  else if(walk == GHIP_WALK_SHORTRANGE)
-    launch_walk<GHIP_WALK_SHORTRANGE>(ctx, ctx->gt, nt, tgt, tx, ty, tz, ts, to, k, counter);
-  else
-    launch_walk<GHIP_WALK_EWALD>(ctx, ctx->gt, nt, tgt, tx, ty, tz, ts, to, k, counter);
+  launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, tgt, P<double>(ctx->sx),
+                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
+                  P<double>(ctx->soldacc), k, counter);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[evi + 1], st));
 
-  k_scatter_grav<<<cdiv(nt, 256), 256, 0, st>>>(
-    nt, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay), P<double>(ctx->taz),
-    P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<int>(ctx->f[GHIP_F_GRAVCOST]),
-    walk == GHIP_WALK_EWALD ? 1 : 0);
+  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
+    nt, nsub, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
+    P<double>(ctx->taz), P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
+    P<int>(ctx->f[GHIP_F_GRAVCOST]), walk == GHIP_WALK_EWALD ? 1 : 0, k.debug_steps);
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
@@ -643,8 +409,8 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
   GravK k;
   GCHK(prepare_tables(ctx, p, walk, k));
   hipStream_t st = ctx->stream;
-  // staging: x,y,z,oldacc,soft (f64[nt] each) + type (i32[nt])
-  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nt * (5 * 8 + 4) + 64));
+  // staging: x,y,z,oldacc,soft (f64[nt]) + combined acc (3 f64[nt]) + type, cost (i32[nt])
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nt * (8 * 8 + 2 * 4) + 64));
   std::vector<double> h((size_t) nt * 4);
   for(int a = 0; a < nt; a++)
     {
@@ -654,34 +420,29 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
       h[3 * (size_t) nt + a] = oldacc[a];
     }
   double *dx = P<double>(ctx->stage), *dy = dx + nt, *dz = dy + nt, *dold = dz + nt,
-         *dsoft = dold + nt;
-  int *dtype = reinterpret_cast<int *>(dsoft + nt);
+         *dsoft = dold + nt, *dacc = dsoft + nt;
+  int *dtype = reinterpret_cast<int *>(dacc + 3 * (size_t) nt), *dcost = dtype + nt;
   HIPCHK(hipMemcpyAsync(dx, h.data(), (size_t) nt * 32, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(dtype, type, (size_t) nt * 4, hipMemcpyHostToDevice, st));
   k_soft_of_type_g<<<cdiv(nt, 256), 256, 0, st>>>(nt, dtype, p->ForceSoftening[0],
                                                   p->ForceSoftening[1], p->ForceSoftening[2],
                                                   p->ForceSoftening[3], p->ForceSoftening[4],
                                                   p->ForceSoftening[5], dsoft);
-  GCHK(ghip_ensure(ctx, ctx->tax, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tay, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->taz, (size_t) nt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tcost, (size_t) nt * 4));
+  WalkSeg sg;
+  int nbuckets;
+  int nsub = walk_layout(ctx->gt, nt, sg, &nbuckets);
+  GCHK(ensure_partials(ctx, nt, nsub));
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 2;
-  if(walk == GHIP_WALK_NEWTON)
-    launch_walk<GHIP_WALK_NEWTON>(ctx, ctx->gt, nt, nullptr, dx, dy, dz, dsoft, dold, k, counter);
-  else if(walk == GHIP_WALK_SHORTRANGE)
-    launch_walk<GHIP_WALK_SHORTRANGE>(ctx, ctx->gt, nt, nullptr, dx, dy, dz, dsoft, dold, k,
-                                      counter);
-  else
-    launch_walk<GHIP_WALK_EWALD>(ctx, ctx->gt, nt, nullptr, dx, dy, dz, dsoft, dold, k, counter);
+  launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
+                  counter);
+  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, nsub, nullptr, nullptr, P<double>(ctx->tax),
+                                               P<double>(ctx->tay), P<double>(ctx->taz),
+                                               P<int>(ctx->tcost), nt, dacc, dcost, 0, 0);
   HIPCHK(hipGetLastError());
   std::vector<double> r((size_t) nt * 3);
-  HIPCHK(hipMemcpyAsync(r.data(), ctx->tax.p, (size_t) nt * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(r.data() + nt, ctx->tay.p, (size_t) nt * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(r.data() + 2 * (size_t) nt, ctx->taz.p, (size_t) nt * 8,
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(ninteractions, ctx->tcost.p, (size_t) nt * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(r.data(), dacc, (size_t) nt * 24, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(ninteractions, dcost, (size_t) nt * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for(int a = 0; a < nt; a++)
     {
@@ -741,10 +502,10 @@ extern "C" int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p)
                                                P<double>(ctx->tax), P<double>(ctx->tay),
                                                P<double>(ctx->taz));
   HIPCHK(hipMemsetAsync(ctx->tcost.p, 0, (size_t) nt * 4, st));
-  k_scatter_grav<<<cdiv(nt, 256), 256, 0, st>>>(
-    nt, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay), P<double>(ctx->taz),
-    P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<int>(ctx->f[GHIP_F_GRAVCOST]),
-    0);
+  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
+    nt, 1, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
+    P<double>(ctx->taz), P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
+    P<int>(ctx->f[GHIP_F_GRAVCOST]), 0, 0);
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }

@@ -36,6 +36,10 @@ struct TreeDev
   DevBuf cpl, cnt, nb;                 // i32[n]: common prefix levels, node counts, exclusive scan
   // pre-order element list
   DevBuf xm, cl, lk, aux;              // double4[nelem], double4[nelem], int4[nelem], f64[nelem]
+  // walk segments (ghip_walk.h): start[ns+1], nanc[ns], anc[ns][GHIP_MAXANC]
+  DevBuf seg_start, seg_nanc, seg_anc;
+  int ns = 1;
+  DevBuf mq;                           // WalkElem[nelem]: 128-byte walk records (gravity tree)
   bool built = false;
 };
 
@@ -127,6 +131,7 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx);
 int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst);
 // gravity.hip
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
+int ghip_build_segments(ghip_ctx *ctx, TreeDev &t);
 // sph.hip
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p);

@@ -567,6 +567,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
     {
       GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
       k_inverse_perm<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->gt.perm), P<int>(ctx->gt.iperm));
+      GCHK(ghip_build_segments(ctx, ctx->gt));
       GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
       GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
       GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
