@@ -52,11 +52,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the force path has no CPU fallback")
+    # BENCH_BACKEND=gloo: self-test of the multi-rank path with all ranks on GPU 0 (RCCL refuses
+    # two ranks on one device); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from common import Problem  # seeded workload definition shared with the parity tests
     B = importlib.import_module("gadget-leicester_amd.bindings")
@@ -76,6 +84,14 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def allreduce(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h
 
     # step 0 of a run (accel.c:61-68): Barnes-Hut pass to obtain OldAcc, then relative criterion
     fp.set_field(B.F_OLDACC, np.zeros(pr.n))
@@ -101,12 +117,12 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = allreduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # whole-job interaction counts for the roofline line
         c = torch.tensor([grav_int, ewald_int, dens_ngb, hyd_pairs], dtype=torch.float64,
                          device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        c = allreduce(c, dist.ReduceOp.SUM)
         grav_int_all = float(c[0].item())
     else:
         grav_int_all = float(grav_int)

@@ -92,7 +92,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
 static void free_tree(TreeDev &t)
 {
   DevBuf *bs[] = {&t.key, &t.skey, &t.idx, &t.perm, &t.iperm, &t.cpl, &t.cnt, &t.nb,
-                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq};
+                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2};
   for(DevBuf *b : bs)
     free_buf(*b);
 }

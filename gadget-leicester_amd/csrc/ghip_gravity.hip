@@ -97,7 +97,7 @@ __global__ void k_pack_xyzm(int n, const double *__restrict__ x, const double *_
 // Ewald table (ewald_init / ewald_force, forcetree.c:4402-4527, 4727-4778): alpha = 2,
 // |n|,|h| <= 4, one octant of (EN+1)^3 points at x = 0.5*(i,j,k)/EN, scaled by 1/BoxSize^2
 // ---------------------------------------------------------------------------------------------
-__global__ void k_ewald_table(double inv_box2, double4 *__restrict__ tab)
+__global__ void k_ewald_table(double inv_box2, EwEntry *__restrict__ tab)
 {
   const int E1 = GHIP_EN + 1;
   int nidx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,7 +143,8 @@ __global__ void k_ewald_table(double inv_box2, double4 *__restrict__ tab)
                 }
             }
     }
-  tab[nidx] = make_double4(f0 * inv_box2, f1 * inv_box2, f2 * inv_box2, 0.0);
+  EwEntry out = {f0 * inv_box2, f1 * inv_box2, f2 * inv_box2};
+  tab[nidx] = out;
 }
 
 extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
@@ -152,9 +153,9 @@ extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ewald_init: bad BoxSize");
   const int E1 = GHIP_EN + 1;
   const int nt = E1 * E1 * E1;
-  GCHK(ghip_ensure(ctx, ctx->ewtab, (size_t) nt * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, ctx->ewtab, (size_t) nt * sizeof(EwEntry)));
   k_ewald_table<<<cdiv(nt, 64), 64, 0, ctx->stream>>>(1.0 / (BoxSize * BoxSize),
-                                                      P<double4>(ctx->ewtab));
+                                                      P<EwEntry>(ctx->ewtab));
   HIPCHK(hipGetLastError());
   ctx->ew_box = BoxSize;
   return GHIP_OK;
@@ -167,11 +168,11 @@ extern "C" int ghip_ewald_get_table(ghip_ctx *ctx, double *host)
   const int E1 = GHIP_EN + 1;
   const size_t nt = (size_t) E1 * E1 * E1;
   std::vector<double> tmp(nt * 4);
-  HIPCHK(hipMemcpyAsync(tmp.data(), ctx->ewtab.p, nt * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(tmp.data(), ctx->ewtab.p, nt * 24, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for(size_t q = 0; q < nt; q++)
     for(int c = 0; c < 3; c++)
-      host[c * nt + q] = tmp[4 * q + c];
+      host[c * nt + q] = tmp[3 * q + c];
   return GHIP_OK;
 }
 
@@ -188,6 +189,7 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
   k.fac_intp = (p->BoxSize > 0) ? 2 * GHIP_EN / p->BoxSize : 0;
   k.debug_steps = getenv("GHIP_DEBUG_STEPS") ? 1 : 0;
+  k.xcd_remap = (getenv("GHIP_WALK_XCD") && atoi(getenv("GHIP_WALK_XCD")) == 0) ? 0 : 1;
   if(walk == GHIP_WALK_SHORTRANGE)
     {
       if(!(p->Asmth > 0) || !(p->Rcut > 0))
@@ -241,10 +243,12 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t)
   GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) ns * GHIP_MAXANC * 4));
   k_build_segments<<<cdiv(ns + 1, 64), 64, 0, ctx->stream>>>(
     t.nelem, P<int4>(t.lk), ns, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
-  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkElem)));
+  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkHot)));
+  GCHK(ghip_ensure(ctx, t.mq2, (size_t) (t.nelem + 1) * sizeof(WalkCold)));
   k_fill_elems<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double4>(t.xm),
                                                            P<double4>(t.cl), P<int4>(t.lk),
-                                                           P<double>(t.aux), P<WalkElem>(t.mq));
+                                                           P<double>(t.aux), P<WalkHot>(t.mq),
+                                                           P<WalkCold>(t.mq2));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
@@ -253,6 +257,12 @@ static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
 {
   sg.ns = t.ns;
   sg.nsub = t.ns < GHIP_MAXSUB ? t.ns : GHIP_MAXSUB;
+  if(getenv("GHIP_WALK_SUBS"))
+    {
+      int v = atoi(getenv("GHIP_WALK_SUBS"));
+      if(v >= 1 && v <= t.ns)
+        sg.nsub = v;
+    }
   if(sg.nsub < 1)
     sg.nsub = 1;
   sg.start = P<int>(t.seg_start);
@@ -283,13 +293,13 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
   if(k.periodic)
     k_grav_walk<MODE, true><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
-      t.nelem, P<WalkElem>(t.mq), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-      P<float>(ctx->srtab), P<double4>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
+      t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+      P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
       P<double>(ctx->taz), P<int>(ctx->tcost), counter);
   else
     k_grav_walk<MODE, false><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
-      t.nelem, P<WalkElem>(t.mq), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-      P<float>(ctx->srtab), P<double4>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
+      t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
+      P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
       P<double>(ctx->taz), P<int>(ctx->tcost), counter);
 }
 

@@ -39,7 +39,7 @@ struct TreeDev
   // walk segments (ghip_walk.h): start[ns+1], nanc[ns], anc[ns][GHIP_MAXANC]
   DevBuf seg_start, seg_nanc, seg_anc;
   int ns = 1;
-  DevBuf mq;                           // WalkElem[nelem]: 128-byte walk records (gravity tree)
+  DevBuf mq, mq2;                      // WalkHot[nelem], WalkCold[nelem]: walk records (gravity tree)
   bool built = false;
 };
 

@@ -6,8 +6,8 @@
 //
 // Mapping.  A BUCKET is 64 targets consecutive along the space-filling curve; a wavefront's 64
 // lanes are those targets.  The tree is ONE pre-order element list (ghip_tree.hip); the element
-// index a wave looks at is wave-uniform, so node/particle records arrive through the scalar
-// cache (s_load_dwordx8) and are broadcast for free.  Every lane applies the reference's
+// index a wave looks at is wave-uniform, so element records arrive through the scalar path
+// (s_load_dwordx16) and are broadcast for free.  Every lane applies the reference's
 // PER-PARTICLE opening criterion to the node:
 //   * a lane that accepts the node interacts with its monopole and stores the node's skip index:
 //     it ignores every element below that node (my_skip);
@@ -22,7 +22,14 @@
 // start; <= 22 of them, precomputed) WITHOUT interacting -- an ancestor's interaction belongs to
 // the segment that contains the ancestor's own element.  Ownership by element index makes every
 // interaction happen exactly once; the S partial sums per target are added in fixed order
-// afterwards (k_combine_grav), so results are deterministic.  No MFMA: irregular fp64 work.
+// afterwards (k_combine_grav), so results are deterministic.
+//
+// Latency.  The walk is a pointer chase: the next element is known only after the vote.  Two
+// things keep the SIMDs fed: (i) the record a step needs is ONE 64-byte scalar load (the "hot"
+// half: monopole, opening-criterion operands, links); the "cold" half (cell centre, len) is
+// fetched only when a lane may sit inside the cell or a special walk needs it; (ii) each wavefront
+// advances TWO of its segments at once -- both loads are in flight together, then both elements
+// are processed -- so a step costs half a memory latency.  No MFMA: irregular fp64 work.
 #pragma once
 #include "ghip_internal.h"
 
@@ -36,6 +43,7 @@ struct GravK
   double boxsize, boxhalf;
   int periodic, unequal;
   int debug_steps;     // GHIP_DEBUG_STEPS=1: GRAVCOST receives the wave's visited-element count
+  int xcd_remap;       // GHIP_WALK_XCD=0 disables the XCD-contiguous block order
   double rcut, rcut2, asmthfac;  // shortrange
   double fac_intp;     // ewald: 2*EN/BoxSize
 };
@@ -48,6 +56,58 @@ struct WalkSeg
   const int *__restrict__ nanc;    // [ns]
   const int *__restrict__ anc;     // [ns][GHIP_MAXANC] ancestors of start[k], root first
 };
+
+// hot half of an element (64 B):  x, y, z, mass | (mass*len)*len, len*len | skip, pidx | aux
+//   node: centre of mass, opening-criterion operands in the reference's operation order
+//   (forcetree.c:2085), aux = max softening below (negative: mixed softenings)
+//   particle: position, 0, 0, aux = its softening
+// cold half (64 B): cx, cy, cz, len | 0.6*len | spare
+struct __attribute__((aligned(64))) WalkHot
+{
+  double x, y, z, m;
+  double mlen2, len2;
+  int skip, pidx;
+  double aux;
+};
+struct __attribute__((aligned(64))) WalkCold
+{
+  double cx, cy, cz, len;
+  double len06;
+  double spare[3];
+};
+
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// one grid point of the Ewald correction table: 24 bytes, no padding (the look-up is bound by
+// the bytes the 8 corner gathers move through the vector-memory path)
+struct EwEntry
+{
+  double x, y, z;
+};
+
+__device__ __forceinline__ double d_f64(const v16i &v, int i)
+{
+  return __hiloint2double(v[2 * i + 1], v[2 * i]);
+}
+
+// issue a 64-byte scalar load of record `e` (wave-uniform); the caller waits with d_wait_*
+template <class T>
+__device__ __forceinline__ void d_issue_load(const T *__restrict__ base, int e, v16i &R)
+{
+  unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
+  unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
+  const T *p = reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(R) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void d_wait1(v16i &A)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
+}
+__device__ __forceinline__ void d_wait2(v16i &A, v16i &B)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) : : "memory");
+}
 
 // 1/sqrt(x) to full fp64 precision from the hardware seed (v_rsq_f64, ~2^-23 relative) with one
 // third-order step: e = 1 - x*y^2,  y <- y*(1 + e/2 + 3e^2/8)   (error O(e^3) ~ 2^-69)
@@ -83,7 +143,7 @@ __device__ __forceinline__ double d_grav_fac(double mass, double r2, double h, d
 }
 
 // trilinear Ewald look-up, forcetree.c:3097-3170.  tab: double4 (fx,fy,fz,0) per grid point.
-__device__ __forceinline__ void d_ewald_interp(const double4 *__restrict__ tab, double fac_intp,
+__device__ __forceinline__ void d_ewald_interp(const EwEntry *__restrict__ tab, double fac_intp,
                                                double dx, double dy, double dz, double &fx,
                                                double &fy, double &fz)
 {
@@ -123,9 +183,9 @@ __device__ __forceinline__ void d_ewald_interp(const double4 *__restrict__ tab, 
   double f3 = (1 - u) * (v) * (1 - w), f4 = (1 - u) * (v) * (w);
   double f5 = (u) * (1 - v) * (1 - w), f6 = (u) * (1 - v) * (w);
   double f7 = (u) * (v) * (1 - w), f8 = (u) * (v) * (w);
-  const double4 *b = tab + ((size_t) i * E1 + j) * E1 + k;
-  double4 t1 = b[0], t2 = b[1], t3 = b[E1], t4 = b[E1 + 1];
-  double4 t5 = b[E1 * E1], t6 = b[E1 * E1 + 1], t7 = b[E1 * E1 + E1], t8 = b[E1 * E1 + E1 + 1];
+  const EwEntry *b = tab + ((size_t) i * E1 + j) * E1 + k;
+  EwEntry t1 = b[0], t2 = b[1], t3 = b[E1], t4 = b[E1 + 1];
+  EwEntry t5 = b[E1 * E1], t6 = b[E1 * E1 + 1], t7 = b[E1 * E1 + E1], t8 = b[E1 * E1 + E1 + 1];
   fx = sx * (t1.x * f1 + t2.x * f2 + t3.x * f3 + t4.x * f4 + t5.x * f5 + t6.x * f6 + t7.x * f7 +
              t8.x * f8);
   fy = sy * (t1.y * f1 + t2.y * f2 + t3.y * f3 + t4.y * f4 + t5.y * f5 + t6.y * f6 + t7.y * f7 +
@@ -134,52 +194,13 @@ __device__ __forceinline__ void d_ewald_interp(const double4 *__restrict__ tab, 
              t8.z * f8);
 }
 
-// One tree element as the walk reads it: 128 bytes, fetched with two back-to-back
-// s_load_dwordx16 so that a step costs ONE memory latency (the element list of the 64^3+64^3
-// configuration is ~100 MB: it lives in the Infinity Cache, ~550 cycles away).
-//   dwords  0- 7  x, y, z, mass          (node: centre of mass; particle: position)
-//   dwords  8-15  cx, cy, cz, len        (node geometry; particle: len = 0)
-//   dwords 16-23  len^2, mass*len^2, 0.6*len, aux   (opening-criterion operands, reference's
-//                                                    operation order (mass*len)*len)
-//   dwords 24-27  skip, pidx, pstart, pcount
-struct __attribute__((aligned(128))) WalkElem
-{
-  double x, y, z, m;
-  double cx, cy, cz, len;
-  double len2, mlen2, len06, aux;
-  int skip, pidx, pstart, pcount;
-  int pad[4];
-};
-
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-struct ElemRegs
-{
-  v16i lo, hi;
-};
-
-__device__ __forceinline__ double d_f64(const v16i &v, int i)
-{
-  return __hiloint2double(v[2 * i + 1], v[2 * i]);
-}
-
-// wave-uniform element index -> both halves of the record in SGPRs, one wait
-__device__ __forceinline__ void d_load_elem(const WalkElem *__restrict__ elems, int e, ElemRegs &R)
-{
-  const WalkElem *p = elems + e;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(R.lo), "=&s"(R.hi)
-               : "s"(p)
-               : "memory");
-}
-
+// per-lane target state shared by both in-flight segments
 struct WalkLane
 {
   double pos_x, pos_y, pos_z, h_i, aold;
   double h2;   // h_i^2
   double acc_x, acc_y, acc_z;
   int nint;
-  int my_skip;
 };
 
 // NEAREST (forcetree.c:49) with one compare: |x| > boxhalf ? x - copysign(box, x) : x
@@ -189,60 +210,90 @@ __device__ __forceinline__ double d_nearest1(double x, double boxsize, double bo
   return (fabs(x) > boxhalf) ? x - copysign(boxsize, x) : x;
 }
 
-// One element of the list for all 64 lanes.  OWNED = false replays only the opening decision
-// (ancestor of a segment).  Returns the next element index (wave-uniform).
-// mq[e] = (len^2, mass*len^2, 0.6*len, aux) with the reference's operation order
-// ((mass*len)*len, forcetree.c:2085), so every comparison sees the same doubles.
+// One element of the list for all 64 lanes.  H = hot record (already in SGPRs).  OWNED = false
+// replays only the opening decision (ancestor of a segment).  Returns the next element index
+// (wave-uniform).
 template <int MODE, bool PERIODIC, bool OWNED>
-__device__ __forceinline__ int d_walk_element(int e, const ElemRegs &R, const GravK &p,
+__device__ __forceinline__ int d_walk_element(int e, const v16i &H,
+                                              const WalkCold *__restrict__ cold, const GravK &p,
                                               const float *__restrict__ srtab,
-                                              const double4 *__restrict__ ewtab, WalkLane &W)
+                                              const EwEntry *__restrict__ ewtab, WalkLane &W,
+                                              int &my_skip)
 {
-  const double4 v = make_double4(d_f64(R.lo, 0), d_f64(R.lo, 1), d_f64(R.lo, 2), d_f64(R.lo, 3));
-  const int4 k = make_int4(R.hi[8], R.hi[9], R.hi[10], R.hi[11]);
-  const bool act = (e >= W.my_skip);
+  const double ex = d_f64(H, 0), ey = d_f64(H, 1), ez = d_f64(H, 2), mass = d_f64(H, 3);
+  const double mlen2 = d_f64(H, 4), len2 = d_f64(H, 5);
+  const int skip = H[12], pidx = H[13];
+  const double aux = d_f64(H, 7);
+  const bool act = (e >= my_skip);
   int next;
 
-  double dx = v.x - W.pos_x, dy = v.y - W.pos_y, dz = v.z - W.pos_z;
+  double dx = ex - W.pos_x, dy = ey - W.pos_y, dz = ez - W.pos_z;
   if(MODE == GHIP_WALK_EWALD || PERIODIC)
     {
+      // (a wave-uniform "does any lane wrap?" branch per axis was measured slower than the
+      // straight compare+select: 14.1 vs 12.8 ms at c2)
       dx = d_nearest1(dx, p.boxsize, p.boxhalf);
       dy = d_nearest1(dy, p.boxsize, p.boxhalf);
       dz = d_nearest1(dz, p.boxsize, p.boxhalf);
     }
   const double r2 = dx * dx + dy * dy + dz * dz;
-  const double mass = v.w;
   double h = W.h_i, h2 = W.h2;
   bool interact = act;
 
-  if(LK_IS_PARTICLE(k))
+  if(pidx >= 0)
     {
       next = e + 1;
       if(MODE != GHIP_WALK_EWALD && p.unequal)
         {
-          double sj = d_f64(R.hi, 3);
-          if(h < sj)
+          if(h < aux)
             {
-              h = sj;
+              h = aux;
               h2 = h * h;
             }
         }
     }
   else
     {
-      const double4 c = make_double4(d_f64(R.lo, 4), d_f64(R.lo, 5), d_f64(R.lo, 6), d_f64(R.lo, 7));
-      const double4 q = make_double4(d_f64(R.hi, 0), d_f64(R.hi, 1), d_f64(R.hi, 2), d_f64(R.hi, 3));
-      const double len = c.w;
       bool open = false;
+      // first part of the criterion needs only the hot record (forcetree.c:2074-2091)
+      bool far_enough = false;   // passed the distance test, box test still pending
       if(act)
         {
+          if(p.theta != 0)
+            open = (len2 > r2 * p.theta * p.theta);
+          else
+            {
+              open = (mlen2 > r2 * r2 * W.aold);
+              far_enough = !open;
+            }
+        }
+      // the cold half (cell centre, len) is needed for:
+      //  * the "inside the 1.2*len box" rule of the relative criterion (forcetree.c:2093-2104):
+      //    only possible when r2 < 3.63*len^2 (centre of mass inside the cell, box half-width
+      //    0.6*len: |x - s| < (0.6 + 0.5)*sqrt(3)*len), tested conservatively with 4*len^2
+      //  * the short-range cut-off pruning and the Ewald override
+      bool need_cold;
+      if(MODE == GHIP_WALK_NEWTON)
+        need_cold = far_enough && (r2 < 4.0 * len2);
+      else if(MODE == GHIP_WALK_SHORTRANGE)
+        need_cold = act && ((r2 > p.rcut2) || (far_enough && (r2 < 4.0 * len2)));
+      else
+        need_cold = act && (open || (far_enough && (r2 < 4.0 * len2)));
+      if(__any(need_cold))
+        {
+          v16i C;
+          d_issue_load(cold, e, C);
+          d_wait1(C);
+          const double cx = d_f64(C, 0), cy = d_f64(C, 1), cz = d_f64(C, 2), len = d_f64(C, 3);
+          const double len06 = d_f64(C, 4);
           if(MODE == GHIP_WALK_SHORTRANGE)
             {
-              // forcetree.c:2598-2632: whole cell beyond the cut-off -> drop the branch
-              if(r2 > p.rcut2)
+              // forcetree.c:2598-2632: whole cell beyond the cut-off -> drop the branch.  The
+              // reference tests this BEFORE the opening criterion.
+              if(act && r2 > p.rcut2)
                 {
                   double eff = p.rcut + 0.5 * len;
-                  double d0 = c.x - W.pos_x, d1 = c.y - W.pos_y, d2 = c.z - W.pos_z;
+                  double d0 = cx - W.pos_x, d1 = cy - W.pos_y, d2 = cz - W.pos_z;
                   if(PERIODIC)
                     {
                       d0 = d_nearest1(d0, p.boxsize, p.boxhalf);
@@ -252,56 +303,50 @@ __device__ __forceinline__ int d_walk_element(int e, const ElemRegs &R, const Gr
                   if(fabs(d0) > eff || fabs(d1) > eff || fabs(d2) > eff)
                     {
                       interact = false;
-                      W.my_skip = k.x;
+                      open = false;
+                      far_enough = false;
+                      my_skip = skip;
                     }
                 }
             }
-          if(interact)
+          if(far_enough)
+            open = (fabs(cx - W.pos_x) < len06) && (fabs(cy - W.pos_y) < len06) &&
+                   (fabs(cz - W.pos_z) < len06);
+          if(MODE == GHIP_WALK_EWALD)
             {
-              // opening criterion, forcetree.c:2074-2105
-              if(p.theta != 0)
-                open = (q.x > r2 * p.theta * p.theta);
-              else
+              // forcetree.c:3039-3088: the correction is smooth, so an "open" verdict is
+              // overridden unless the cell straddles the half-box or is large
+              if(act && open)
                 {
-                  open = (q.y > r2 * r2 * W.aold);
-                  if(!open)
-                    open = (fabs(c.x - W.pos_x) < q.z) && (fabs(c.y - W.pos_y) < q.z) &&
-                           (fabs(c.z - W.pos_z) < q.z);
+                  double u0 = d_nearest1(cx - W.pos_x, p.boxsize, p.boxhalf);
+                  double u1 = d_nearest1(cy - W.pos_y, p.boxsize, p.boxhalf);
+                  double u2 = d_nearest1(cz - W.pos_z, p.boxsize, p.boxhalf);
+                  double lim = 0.5 * (p.boxsize - len);
+                  open = (fabs(u0) > lim) || (fabs(u1) > lim) || (fabs(u2) > lim) ||
+                         (len > 0.20 * p.boxsize);
                 }
-              if(MODE == GHIP_WALK_EWALD)
-                {
-                  // forcetree.c:3039-3088: the correction is smooth, so an "open" verdict is
-                  // overridden unless the cell straddles the half-box or is large
-                  if(open)
-                    {
-                      double u0 = d_nearest1(c.x - W.pos_x, p.boxsize, p.boxhalf);
-                      double u1 = d_nearest1(c.y - W.pos_y, p.boxsize, p.boxhalf);
-                      double u2 = d_nearest1(c.z - W.pos_z, p.boxsize, p.boxhalf);
-                      double lim = 0.5 * (p.boxsize - len);
-                      open = (fabs(u0) > lim) || (fabs(u1) > lim) || (fabs(u2) > lim) ||
-                             (len > 0.20 * p.boxsize);
-                    }
-                }
-              else if(p.unequal && !open)
-                {
-                  // forcetree.c:2108-2124
-                  double a = q.w;
-                  double ms = fabs(a);
-                  if(h < ms)
-                    {
-                      h = ms;
-                      h2 = h * h;
-                      if(r2 < h2 && a < 0)
-                        open = true;
-                    }
-                }
-              if(open)
-                interact = false;
-              else
-                W.my_skip = k.x;
             }
         }
-      next = __any(open) ? e + 1 : k.x;
+      if(interact)
+        {
+          if(MODE != GHIP_WALK_EWALD && p.unequal && !open)
+            {
+              // forcetree.c:2108-2124
+              double ms = fabs(aux);
+              if(h < ms)
+                {
+                  h = ms;
+                  h2 = h * h;
+                  if(r2 < h2 && aux < 0)
+                    open = true;
+                }
+            }
+          if(open)
+            interact = false;
+          else
+            my_skip = skip;
+        }
+      next = __any(open) ? e + 1 : skip;
     }
 
   if(OWNED && interact)
@@ -355,23 +400,64 @@ __device__ __forceinline__ int d_wave_min_i32(int v)
   return v;
 }
 
+// cursor over the segments one wavefront owns through one of its two slots
+struct SegCursor
+{
+  int kseg;      // current segment (>= ns: exhausted)
+  int e, s1;     // current element, end of segment
+};
+
+// enter segment `c.kseg`: replay the ancestors, position the cursor at the first element any lane
+// still needs.  Returns false when the slot has no segment left.
+template <int MODE, bool PERIODIC>
+__device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const WalkSeg &sg,
+                                                const WalkHot *__restrict__ hot,
+                                                const WalkCold *__restrict__ cold, const GravK &p,
+                                                const float *__restrict__ srtab,
+                                                const EwEntry *__restrict__ ewtab, bool valid,
+                                                WalkLane &W, int &my_skip, unsigned int &steps)
+{
+  while(c.kseg < sg.ns)
+    {
+      const int s0 = sg.start[c.kseg];
+      c.s1 = sg.start[c.kseg + 1];
+      my_skip = valid ? 0 : 0x7fffffff;
+      const int na = sg.nanc[c.kseg];
+      for(int a = 0; a < na; a++)
+        {
+          int ea = __builtin_amdgcn_readfirstlane(sg.anc[c.kseg * GHIP_MAXANC + a]);
+          v16i H;
+          d_issue_load(hot, ea, H);
+          d_wait1(H);
+          d_walk_element<MODE, PERIODIC, false>(ea, H, cold, p, srtab, ewtab, W, my_skip);
+          steps++;
+        }
+      int first = d_wave_min_i32(my_skip);   // every lane below an accepted ancestor: jump
+      c.e = __builtin_amdgcn_readfirstlane(first > s0 ? first : s0);
+      if(c.e < c.s1)
+        return true;
+      c.kseg += stride;
+    }
+  return false;
+}
+
 // partial results: [nsub][nt] per component.
 // Grid: a multiple of 8 blocks; the block index is remapped so that each XCD (blocks are dealt
 // round-robin over the 8 XCDs) works through ONE contiguous eighth of the buckets: neighbouring
 // buckets read the same deep tree nodes, which then stay in that XCD's 4 MB L2.
 template <int MODE, bool PERIODIC>
 __global__ void __launch_bounds__(GHIP_BLOCK)
-k_grav_walk(int nelem, const WalkElem *__restrict__ elems, WalkSeg sg, int nt,
-            const int *__restrict__ tgt, const double *__restrict__ tx,
+k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restrict__ cold,
+            WalkSeg sg, int nt, const int *__restrict__ tgt, const double *__restrict__ tx,
             const double *__restrict__ ty, const double *__restrict__ tz,
             const double *__restrict__ tsoft, const double *__restrict__ toldacc, GravK p,
-            const float *__restrict__ srtab, const double4 *__restrict__ ewtab,
+            const float *__restrict__ srtab, const EwEntry *__restrict__ ewtab,
             double *__restrict__ pax, double *__restrict__ pay, double *__restrict__ paz,
             int *__restrict__ pcost, unsigned long long *__restrict__ counter)
 {
   const int lane = threadIdx.x & 63;
   const int per_xcd = gridDim.x >> 3;
-  const int lblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int lblock = p.xcd_remap ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const int wave = (lblock * GHIP_BLOCK + threadIdx.x) >> 6;
   const int bucket = wave / sg.nsub;
   const int sub = wave - bucket * sg.nsub;
@@ -398,29 +484,61 @@ k_grav_walk(int nelem, const WalkElem *__restrict__ elems, WalkSeg sg, int nt,
   W.acc_x = W.acc_y = W.acc_z = 0;
   W.nint = 0;
   unsigned int steps = 0;
-  ElemRegs R;
 
-  for(int kseg = sub; kseg < sg.ns; kseg += sg.nsub)
+  // two slots: A owns segments sub, sub+2S, ...; B owns sub+S, sub+3S, ...
+  SegCursor A, B;
+  int skipA = 0, skipB = 0;
+  A.kseg = sub;
+  B.kseg = sub + sg.nsub;
+  const int stride = 2 * sg.nsub;
+  bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid, W,
+                                               skipA, steps);
+  bool liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid, W,
+                                               skipB, steps);
+  while(liveA && liveB)
     {
-      const int s0 = sg.start[kseg], s1 = sg.start[kseg + 1];
-      W.my_skip = valid ? 0 : 0x7fffffff;
-      // replay the opening decisions at the ancestors of this segment's first element
-      const int na = sg.nanc[kseg];
-      for(int a = 0; a < na; a++)
+      v16i HA, HB;
+      d_issue_load(hot, A.e, HA);
+      d_issue_load(hot, B.e, HB);
+      d_wait2(HA, HB);
+      steps += 2;
+      A.e = __builtin_amdgcn_readfirstlane(
+        d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+      B.e = __builtin_amdgcn_readfirstlane(
+        d_walk_element<MODE, PERIODIC, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
+      if(A.e >= A.s1)
         {
-          int ea = __builtin_amdgcn_readfirstlane(sg.anc[kseg * GHIP_MAXANC + a]);
-          d_load_elem(elems, ea, R);
-          d_walk_element<MODE, PERIODIC, false>(ea, R, p, srtab, ewtab, W);
-          steps++;
+          A.kseg += stride;
+          liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                  W, skipA, steps);
         }
-      int first = d_wave_min_i32(W.my_skip);   // every lane below an accepted ancestor: jump
-      int e = first > s0 ? first : s0;
-      while(e < s1)
+      if(B.e >= B.s1)
         {
-          e = __builtin_amdgcn_readfirstlane(e);
-          steps++;
-          d_load_elem(elems, e, R);
-          e = d_walk_element<MODE, PERIODIC, true>(e, R, p, srtab, ewtab, W);
+          B.kseg += stride;
+          liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                  W, skipB, steps);
+        }
+    }
+  // drain whichever slot is still live, one element at a time
+  if(liveB)
+    {
+      A = B;
+      skipA = skipB;
+      liveA = true;
+    }
+  while(liveA)
+    {
+      v16i HA;
+      d_issue_load(hot, A.e, HA);
+      d_wait1(HA);
+      steps++;
+      A.e = __builtin_amdgcn_readfirstlane(
+        d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+      if(A.e >= A.s1)
+        {
+          A.kseg += stride;
+          liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                  W, skipA, steps);
         }
     }
 
@@ -511,38 +629,43 @@ __global__ void k_combine_grav(int nt, int nsub, const int *__restrict__ tgt,
     }
 }
 
-// the walk's 128-byte element records from the tree arrays (see WalkElem)
+// the walk's hot/cold element records from the tree arrays (see WalkHot / WalkCold)
 __global__ void k_fill_elems(int nelem, const double4 *__restrict__ xm,
                              const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-                             const double *__restrict__ aux, WalkElem *__restrict__ out)
+                             const double *__restrict__ aux, WalkHot *__restrict__ hot,
+                             WalkCold *__restrict__ cold)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if(e >= nelem)
     return;
   double4 v = xm[e], c = cl[e];
   int4 k = lk[e];
-  WalkElem r;
-  r.x = v.x;
-  r.y = v.y;
-  r.z = v.z;
-  r.m = v.w;
-  r.cx = c.x;
-  r.cy = c.y;
-  r.cz = c.z;
-  r.len = c.w;
+  WalkHot h;
+  h.x = v.x;
+  h.y = v.y;
+  h.z = v.z;
+  h.m = v.w;
+  WalkCold q;
+  q.cx = c.x;
+  q.cy = c.y;
+  q.cz = c.z;
+  q.len = c.w;
   if(LK_IS_PARTICLE(k))
-    r.len2 = r.mlen2 = r.len06 = 0.0;
+    {
+      h.mlen2 = 0.0;
+      h.len2 = 0.0;
+      q.len06 = 0.0;
+    }
   else
     {
-      r.len2 = c.w * c.w;
-      r.mlen2 = v.w * c.w * c.w;
-      r.len06 = 0.60 * c.w;
+      h.mlen2 = v.w * c.w * c.w;   // (mass*len)*len, forcetree.c:2085
+      h.len2 = c.w * c.w;
+      q.len06 = 0.60 * c.w;
     }
-  r.aux = aux[e];
-  r.skip = k.x;
-  r.pidx = k.y;
-  r.pstart = k.z;
-  r.pcount = k.w;
-  r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
-  out[e] = r;
+  h.skip = k.x;
+  h.pidx = k.y;
+  h.aux = aux[e];
+  q.spare[0] = q.spare[1] = q.spare[2] = 0.0;
+  hot[e] = h;
+  cold[e] = q;
 }

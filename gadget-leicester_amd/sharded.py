@@ -43,8 +43,15 @@ class ShardedForceStep:
             return
         mine, allb = self._buffers(group, per)
         self.e.shard_pack(group, mine.data_ptr())
-        self.dist.all_gather_into_tensor(allb, mine)
-        if self.device is not None and str(self.device).startswith("cuda"):
+        on_gpu = self.device is not None and str(self.device).startswith("cuda")
+        if on_gpu and self.dist.get_backend() == "gloo":
+            # self-test configuration (several ranks sharing one GPU): stage through the host
+            host_all = allb.cpu()
+            self.dist.all_gather_into_tensor(host_all, mine.cpu())
+            allb.copy_(host_all)
+        else:
+            self.dist.all_gather_into_tensor(allb, mine)
+        if on_gpu:
             import torch
             torch.cuda.synchronize()
         self.e.shard_unpack(group, allb.data_ptr(), self.world)
