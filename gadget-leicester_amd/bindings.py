@@ -13,14 +13,15 @@ _pkg = importlib.import_module(__package__)
 # enum ghip_field
 (F_POS, F_VEL, F_MASS, F_TYPE, F_OLDACC, F_HSML, F_TIMEBIN, F_TI_BEGSTEP, F_VELPRED, F_ENTROPY,
  F_DTENTROPY, F_GRAVACCEL, F_GRAVCOST, F_NUMNGB, F_DENSITY, F_DHSMLFAC, F_DIVVEL, F_CURLVEL,
- F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_COUNT) = range(22)
+ F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_TI_CURRENT, F_COUNT) = range(23)
 
 _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_POS: (0, 3, 0), F_VEL: (0, 3, 0), F_MASS: (0, 1, 0), F_TYPE: (0, 1, 1), F_OLDACC: (0, 1, 0),
     F_HSML: (0, 1, 0), F_TIMEBIN: (0, 1, 1), F_TI_BEGSTEP: (0, 1, 1), F_VELPRED: (1, 3, 0),
     F_ENTROPY: (1, 1, 0), F_DTENTROPY: (1, 1, 0), F_GRAVACCEL: (0, 3, 0), F_GRAVCOST: (0, 1, 1),
     F_NUMNGB: (1, 1, 0), F_DENSITY: (1, 1, 0), F_DHSMLFAC: (1, 1, 0), F_DIVVEL: (1, 1, 0),
-    F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0)}
+    F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0),
+    F_TI_CURRENT: (0, 1, 1)}
 
 WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD = 0, 1, 2
 EN = 64
@@ -35,7 +36,7 @@ class Layout(C.Structure):
         "p_ti_begstep", "p_type", "p_timebin", "p_hsml", "p_numngb",
         "s_stride", "s_entropy", "s_pressure", "s_velpred", "s_maxsignalvel", "s_density",
         "s_dtentropy", "s_hydroaccel", "s_dhsmlfac", "s_divvel", "s_curlvel", "s_hsml",
-        "s_numngb")]
+        "s_numngb", "p_ti_current")]
 
 
 class GravParams(C.Structure):
@@ -56,6 +57,14 @@ class HydroParams(C.Structure):
                 ("ComovingIntegrationOn", C.c_int), ("hubble_a2", C.c_double),
                 ("fac_mu", C.c_double), ("fac_vsic_fix", C.c_double),
                 ("Timebase_interval", C.c_double), ("raw_dtentropy", C.c_int)]
+
+
+class DriftParams(C.Structure):
+    _fields_ = [("time1", C.c_int), ("Timebase_interval", C.c_double),
+                ("ComovingIntegrationOn", C.c_int), ("logTimeBegin", C.c_double),
+                ("logTimeMax", C.c_double), ("DriftTable", C.c_void_p),
+                ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p),
+                ("MinGasHsml", C.c_double), ("box_wrap", C.c_int), ("BoxSize", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -87,7 +96,8 @@ EXPORTS = [
     "ghip_gravity_ext", "ghip_gravity_finish", "ghip_gravity_direct", "ghip_density",
     "ghip_update_hmax", "ghip_hydro", "ghip_density_evaluate", "ghip_ngb_treefind",
     "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
-    "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count"]
+    "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
+    "ghip_drift"]
 
 
 def lib():
@@ -129,6 +139,7 @@ def lib():
         L.ghip_stream.argtypes = [vp]
         L.ghip_stream.restype = vp
         L.ghip_sync.argtypes = [vp]
+        L.ghip_drift.argtypes = [vp, C.POINTER(DriftParams)]
         L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ghip_shard_pack.argtypes = [vp, C.c_int, vp]
         L.ghip_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -248,6 +259,18 @@ class ForcePath:
 
     def gravity_direct(self, params):
         self._chk(self.L.ghip_gravity_direct(self.h, C.byref(params)))
+
+    def drift(self, time1, timebase, min_gas_hsml=0.0, box_wrap=False, boxsize=1.0, tables=None,
+              log_time_begin=0.0, log_time_max=0.0):
+        p = DriftParams()
+        p.time1, p.Timebase_interval = int(time1), float(timebase)
+        p.MinGasHsml, p.box_wrap, p.BoxSize = float(min_gas_hsml), int(box_wrap), float(boxsize)
+        if tables is not None:
+            self._tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+            p.ComovingIntegrationOn = 1
+            p.logTimeBegin, p.logTimeMax = float(log_time_begin), float(log_time_max)
+            p.DriftTable, p.GravKickTable, p.HydroKickTable = [t.ctypes.data for t in self._tabs]
+        self._chk(self.L.ghip_drift(self.h, C.byref(p)))
 
     def density(self, params):
         self._chk(self.L.ghip_density(self.h, C.byref(params)))

@@ -92,7 +92,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
 static void free_tree(TreeDev &t)
 {
   DevBuf *bs[] = {&t.key, &t.skey, &t.idx, &t.perm, &t.iperm, &t.cpl, &t.cnt, &t.nb,
-                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2};
+                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2, &t.phkey, &t.phorder};
   for(DevBuf *b : bs)
     free_buf(*b);
 }
@@ -162,7 +162,8 @@ static const FieldInfo kField[GHIP_F_COUNT] = {
   /* ENTROPY */ {1, 1, 0},    /* DTENTROPY */ {1, 1, 0}, /* GRAVACCEL */ {0, 3, 0},
   /* GRAVCOST */ {0, 1, 1},   /* NUMNGB */ {1, 1, 0},    /* DENSITY */ {1, 1, 0},
   /* DHSMLFAC */ {1, 1, 0},   /* DIVVEL */ {1, 1, 0},    /* CURLVEL */ {1, 1, 0},
-  /* PRESSURE */ {1, 1, 0},   /* HYDROACCEL */ {1, 3, 0}, /* MAXSIGNALVEL */ {1, 1, 0}};
+  /* PRESSURE */ {1, 1, 0},   /* HYDROACCEL */ {1, 3, 0}, /* MAXSIGNALVEL */ {1, 1, 0},
+  /* TI_CURRENT */ {0, 1, 1}};
 
 static size_t field_count(const ghip_ctx *ctx, int f)
 {
@@ -377,6 +378,10 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
   if(lay->p_ti_begstep >= 0)
     k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
       n, (const char *) ip, lay->p_stride, lay->p_ti_begstep, P<int>(ctx->f[GHIP_F_TI_BEGSTEP]));
+  if(lay->p_ti_current >= 0)
+    k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
+      n, (const char *) ip, lay->p_stride, lay->p_ti_current, P<int>(ctx->f[GHIP_F_TI_CURRENT]));
+  UNPACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
   if(lay->p_hsml >= 0)
     UNPACK64(n, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
   if(ng > 0)
@@ -391,6 +396,7 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
       UNPACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
       UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
       UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
+      UNPACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
     }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));

@@ -34,6 +34,7 @@ struct TreeDev
   // sort
   DevBuf key, skey, idx, perm, iperm;  // u64[n], u64[n], i32[n], i32[n] (sorted->host index), i32[nhost]
   DevBuf cpl, cnt, nb;                 // i32[n]: common prefix levels, node counts, exclusive scan
+  DevBuf phkey, phorder;               // u64[n], i32[n]: tree-order indices in Peano-Hilbert order
   // pre-order element list
   DevBuf xm, cl, lk, aux;              // double4[nelem], double4[nelem], int4[nelem], f64[nelem]
   // walk segments (ghip_walk.h): start[ns+1], nanc[ns], anc[ns][GHIP_MAXANC]

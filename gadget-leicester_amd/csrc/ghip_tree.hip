@@ -80,6 +80,44 @@ __constant__ unsigned char c_ph_perm[8][3] = {{0, 2, 1}, {0, 2, 1}, {2, 1, 0}, {
 __constant__ unsigned char c_ph_flip[8][3] = {{0, 0, 0}, {0, 1, 1}, {0, 0, 0}, {1, 0, 1},
                                               {1, 1, 0}, {1, 1, 0}, {0, 0, 0}, {1, 0, 1}};
 
+// the same curve for one 21-bit triplet (target bucketing: 64 Peano-Hilbert-consecutive particles
+// fill a box 2.7x smaller than 64 Morton-consecutive ones, so the lanes of a wavefront agree on
+// more opening decisions)
+__device__ __forceinline__ unsigned long long d_peano21(int x, int y, int z)
+{
+  int perm0 = 0, perm1 = 1, perm2 = 2, f0 = 0, f1 = 0, f2 = 0;
+  unsigned long long k = 0;
+  for(int b = GHIP_BITS - 1; b >= 0; b--)
+    {
+      int bit[3] = {(x >> b) & 1, (y >> b) & 1, (z >> b) & 1};
+      int w0 = bit[perm0] ^ f0, w1 = bit[perm1] ^ f1, w2 = bit[perm2] ^ f2;
+      int local = w0 * 4 + w1 * 2 + w2;
+      k = (k << 3) | c_ph_base[local];
+      int p[3] = {perm0, perm1, perm2}, f[3] = {f0, f1, f2};
+      int a0 = c_ph_perm[local][0], a1 = c_ph_perm[local][1], a2 = c_ph_perm[local][2];
+      perm0 = p[a0];
+      perm1 = p[a1];
+      perm2 = p[a2];
+      f0 = f[a0] ^ c_ph_flip[local][0];
+      f1 = f[a1] ^ c_ph_flip[local][1];
+      f2 = f[a2] ^ c_ph_flip[local][2];
+    }
+  return k;
+}
+
+__global__ void k_peano_from_pos(int n, const double *__restrict__ x, const double *__restrict__ y,
+                                 const double *__restrict__ z, double cx, double cy, double cz,
+                                 double fac, unsigned long long *__restrict__ key,
+                                 int *__restrict__ idx)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  key[i] = d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac),
+                     (int) ((z[i] - cz) * fac));
+  idx[i] = i;
+}
+
 __global__ void k_peano_from_ints(int n, const int *__restrict__ x, const int *__restrict__ y,
                                   const int *__restrict__ z, int bits,
                                   unsigned long long *__restrict__ key)
@@ -445,6 +483,21 @@ __global__ void k_mark_active(int nact, const int *__restrict__ act, const int *
 // ---------------------------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------------------------
+__global__ void k_iota_tree(int n, int *__restrict__ a)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    a[i] = i;
+}
+
+__global__ void k_gather_i32(int n, const int *__restrict__ idx, const int *__restrict__ src,
+                             int *__restrict__ dst)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = src[idx[i]];
+}
+
 static int cub_tmp(ghip_ctx *ctx, size_t bytes)
 {
   return ghip_ensure(ctx, ctx->cubtmp, bytes + 256);
@@ -529,6 +582,27 @@ static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const do
       else
         k_node_level<false, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
           t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+    }
+  HIPCHK(hipGetLastError());
+
+  // Peano-Hilbert order of the (tree-order) particles: the order in which targets are bucketed
+  GCHK(ghip_ensure(ctx, t.phkey, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, t.phorder, (size_t) n * 4));
+  if(getenv("GHIP_TARGET_ORDER") && !strcmp(getenv("GHIP_TARGET_ORDER"), "morton"))
+    k_iota_tree<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.phorder));
+  else
+    {
+      k_peano_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, sx, sy, sz, ctx->corner[0],
+                                                     ctx->corner[1], ctx->corner[2], fac,
+                                                     P<unsigned long long>(t.key), P<int>(t.idx));
+      size_t tb2 = 0;
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, P<unsigned long long>(t.key),
+                                                P<unsigned long long>(t.phkey), P<int>(t.idx),
+                                                P<int>(t.phorder), n, 0, 63, st));
+      GCHK(cub_tmp(ctx, tb2));
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb2, P<unsigned long long>(t.key),
+                                                P<unsigned long long>(t.phkey), P<int>(t.idx),
+                                                P<int>(t.phorder), n, 0, 63, st));
     }
   HIPCHK(hipGetLastError());
   t.built = true;
@@ -649,8 +723,7 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
   GCHK(ghip_ensure(ctx, list, (size_t) n * 4));
   if(ctx->nactive < 0)
     {
-      k_iota<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(list));
-      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(list.p, t.phorder.p, (size_t) n * 4, hipMemcpyDeviceToDevice, st));
       *count = n;
       return GHIP_OK;
     }
@@ -662,16 +735,18 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
   k_mark_active<<<cdiv(ctx->nactive, 256), 256, 0, st>>>(ctx->nactive, P<int>(ctx->act_host_idx),
                                                           P<int>(t.iperm), host_limit,
                                                           P<int>(ctx->dflags));
-  k_iota<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->dtgt_a));
+  // flags in Peano-Hilbert order, then an order-preserving selection of the PH-ordered indices
+  k_gather_i32<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.phorder), P<int>(ctx->dflags),
+                                             P<int>(ctx->dtgt_a));
   HIPCHK(hipGetLastError());
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
   int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
   size_t tb = 0;
-  HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, P<int>(ctx->dtgt_a), P<int>(ctx->dflags),
+  HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, P<int>(t.phorder), P<int>(ctx->dtgt_a),
                                        P<int>(list), dnum, n, st));
   GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb, P<int>(ctx->dtgt_a),
-                                       P<int>(ctx->dflags), P<int>(list), dnum, n, st));
+  HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb, P<int>(t.phorder),
+                                       P<int>(ctx->dtgt_a), P<int>(list), dnum, n, st));
   HIPCHK(hipMemcpyAsync(count, dnum, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return GHIP_OK;

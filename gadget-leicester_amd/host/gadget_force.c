@@ -166,6 +166,7 @@ void gadget_force_layout(ghip_layout *lay)
   lay->s_curlvel = (int) offsetof(struct sph_particle_data, r);
   lay->s_hsml = (int) offsetof(struct sph_particle_data, Hsml);
   lay->s_numngb = (int) offsetof(struct sph_particle_data, n);
+  lay->p_ti_current = (int) offsetof(struct particle_data, Ti_current);
 }
 
 /* gravtree.c:835-884 */

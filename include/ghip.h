@@ -64,6 +64,7 @@ enum ghip_field
   GHIP_F_PRESSURE,       /* SphP[].Pressure   [ngas] f64 in/out */
   GHIP_F_HYDROACCEL,     /* SphP[].a.HydroAccel [ngas][3] f64 out */
   GHIP_F_MAXSIGNALVEL,   /* SphP[].MaxSignalVel [ngas] f64 out */
+  GHIP_F_TI_CURRENT,     /* P[].Ti_current    [n]    i32 in/out (ghip_drift) */
   GHIP_F_COUNT
 };
 
@@ -79,6 +80,7 @@ typedef struct
   int s_stride, s_entropy, s_pressure, s_velpred, s_maxsignalvel, s_density, s_dtentropy;
   int s_hydroaccel, s_dhsmlfac, s_divvel, s_curlvel;
   int s_hsml, s_numngb; /* when PPP == SphP, else -1 */
+  int p_ti_current;     /* i32 */
 } ghip_layout;
 
 typedef struct
@@ -117,6 +119,19 @@ typedef struct
   int raw_dtentropy;         /* 1: leave DtEntropy as hydro_evaluate's raw sum (hydra.c:1934), skip
                               * hydro_force's conversion to dA/dt (hydra.c:583) */
 } ghip_hydro_params;
+
+/* drift_particle() for every particle + optional do_box_wrapping() (predict.c:129-259, 282-310) */
+typedef struct
+{
+  int time1;                 /* All.Ti_Current to drift to */
+  double Timebase_interval;
+  int ComovingIntegrationOn;
+  double logTimeBegin, logTimeMax;                          /* driftfac.c:20 */
+  const double *DriftTable, *GravKickTable, *HydroKickTable; /* host, 1000 entries each */
+  double MinGasHsml;
+  int box_wrap;              /* also apply do_box_wrapping() with BoxSize */
+  double BoxSize;
+} ghip_drift_params;
 
 /* work counters of the last phase, counted exactly as the reference counts them
  * (SURVEY.md 8d): used for roofline.achieved */
@@ -172,6 +187,10 @@ int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks);
 int ghip_shard_count(ghip_ctx *ctx, int gas, int *per, int *mine);
 int ghip_shard_pack(ghip_ctx *ctx, int group, void *dev_buf);
 int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_all, int nranks);
+
+/* ---- pre-condition of the path: drift the resident particles (replaces the lazy
+ * drift_particle() calls inside the walks, forcetree.c:1911, ngb.c:57) ---- */
+int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p);
 
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],

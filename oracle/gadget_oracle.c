@@ -1583,3 +1583,83 @@ void orc_set_num_threads(int nthreads)
   (void) nthreads;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * drift (pre-condition of the path)
+ * ---------------------------------------------------------------------------------------- */
+
+/* driftfac.c:123-163 get_drift_factor (same form for the two kick tables, :166-247) */
+static double table_factor(const double *tab, int time0, int time1, double timebase,
+                           double logTimeBegin, double logTimeMax)
+{
+  const int NT = 1000; /* DRIFT_TABLE_LENGTH, allvars.h:136 */
+  double a1 = logTimeBegin + time0 * timebase;
+  double a2 = logTimeBegin + time1 * timebase;
+  double u1 = (a1 - logTimeBegin) / (logTimeMax - logTimeBegin) * NT;
+  int i1 = (int) u1;
+  if(i1 >= NT)
+    i1 = NT - 1;
+  double df1 = (i1 <= 1) ? u1 * tab[0] : tab[i1 - 1] + (tab[i1] - tab[i1 - 1]) * (u1 - i1);
+  double u2 = (a2 - logTimeBegin) / (logTimeMax - logTimeBegin) * NT;
+  int i2 = (int) u2;
+  if(i2 >= NT)
+    i2 = NT - 1;
+  double df2 = (i2 <= 1) ? u2 * tab[0] : tab[i2 - 1] + (tab[i2] - tab[i2 - 1]) * (u2 - i2);
+  return df2 - df1;
+}
+
+/* predict.c:129-259 drift_particle for all particles, then predict.c:282-310 do_box_wrapping.
+ * tables = NULL: non-comoving.  Arrays: pos/vel/gravaccel [n][3]; gas arrays [ngas](,3). */
+int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
+              double logTimeBegin, double logTimeMax, double minhsml, int wrap, double boxsize,
+              double *pos, const double *vel, const int *type, int *ti_current, const int *timebin,
+              const int *ti_begstep, const double *gravaccel, double *velpred,
+              const double *hydroaccel, double *density, double *hsml, const double *divvel,
+              const double *entropy, const double *dtentropy, double *pressure)
+{
+  for(int i = 0; i < n; i++)
+    {
+      int time0 = ti_current[i];
+      if(time1 < time0)
+        return 12;
+      if(time1 != time0)
+        {
+          double dt_drift, dt_gravkick, dt_hydrokick;
+          if(tables)
+            {
+              dt_drift = table_factor(tables, time0, time1, timebase, logTimeBegin, logTimeMax);
+              dt_gravkick = table_factor(tables + 1000, time0, time1, timebase, logTimeBegin,
+                                         logTimeMax);
+              dt_hydrokick = table_factor(tables + 2000, time0, time1, timebase, logTimeBegin,
+                                          logTimeMax);
+            }
+          else
+            dt_drift = dt_gravkick = dt_hydrokick = (time1 - time0) * timebase;
+          for(int j = 0; j < 3; j++)
+            pos[3 * i + j] += vel[3 * i + j] * dt_drift;
+          if(i < ngas && type[i] == 0)
+            {
+              for(int j = 0; j < 3; j++)
+                velpred[3 * i + j] += gravaccel[3 * i + j] * dt_gravkick +
+                  hydroaccel[3 * i + j] * dt_hydrokick;
+              density[i] *= exp(-divvel[i] * dt_drift);
+              hsml[i] *= exp(0.333333333333 * divvel[i] * dt_drift);
+              if(hsml[i] < minhsml)
+                hsml[i] = minhsml;
+              int dt_step = (timebin[i] ? (1 << timebin[i]) : 0);
+              double dt_entr = (time1 - (ti_begstep[i] + dt_step / 2)) * timebase;
+              pressure[i] = (entropy[i] + dtentropy[i] * dt_entr) * pow(density[i], GAMMA);
+            }
+          ti_current[i] = time1;
+        }
+      if(wrap)
+        for(int j = 0; j < 3; j++)
+          {
+            while(pos[3 * i + j] < 0)
+              pos[3 * i + j] += boxsize;
+            while(pos[3 * i + j] >= boxsize)
+              pos[3 * i + j] -= boxsize;
+          }
+    }
+  return 0;
+}

@@ -138,6 +138,15 @@ void orc_hydro(const orc_tree *t, const orc_hydro_params *p, int nactive, const 
                const double *curlvel, const int *timebin, double *hydroaccel, double *dtentropy,
                double *maxsignalvel, long long *npairs);
 
+/* ---- drift_particle + do_box_wrapping (predict.c:129-259, 282-310); tables: NULL or
+ * [3][1000] = DriftTable, GravKickTable, HydroKickTable.  Returns 0, or 12 (endrun(12)). ---- */
+int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
+              double logTimeBegin, double logTimeMax, double minhsml, int wrap, double boxsize,
+              double *pos, const double *vel, const int *type, int *ti_current, const int *timebin,
+              const int *ti_begstep, const double *gravaccel, double *velpred,
+              const double *hydroaccel, double *density, double *hsml, const double *divvel,
+              const double *entropy, const double *dtentropy, double *pressure);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int nthreads);
 

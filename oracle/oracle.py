@@ -299,6 +299,28 @@ def gravity_direct(pos, mass, ptype, soft, targets, unequal=False, periodic=Fals
     return acc
 
 
+def drift(time1, timebase, pos, vel, ptype, ti_current, timebin, ti_begstep, gravaccel, velpred,
+          hydroaccel, density, hsml, divvel, entropy, dtentropy, pressure, minhsml=0.0, wrap=False,
+          boxsize=1.0, tables=None, log_time_begin=0.0, log_time_max=0.0):
+    """In-place drift of copies; returns dict of the updated arrays."""
+    n, ngas = len(pos), len(velpred)
+    out = dict(pos=_f64(pos).copy(), ti_current=_i32(ti_current).copy(),
+               velpred=_f64(velpred).copy(), density=_f64(density).copy(), hsml=_f64(hsml).copy(),
+               pressure=_f64(pressure).copy())
+    tabs = None if tables is None else _f64(np.concatenate([np.ravel(t) for t in tables]))
+    L = lib()
+    L.orc_drift.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double,
+                            C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 15
+    rc = L.orc_drift(n, ngas, int(time1), float(timebase), _p(tabs), float(log_time_begin),
+                     float(log_time_max), float(minhsml), int(wrap), float(boxsize),
+                     _p(out["pos"]), _p(_f64(vel)), _p(_i32(ptype)), _p(out["ti_current"]),
+                     _p(_i32(timebin)), _p(_i32(ti_begstep)), _p(_f64(gravaccel)),
+                     _p(out["velpred"]), _p(_f64(hydroaccel)), _p(out["density"]), _p(out["hsml"]),
+                     _p(_f64(divvel)), _p(_f64(entropy)), _p(_f64(dtentropy)), _p(out["pressure"]))
+    out["rc"] = rc
+    return out
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 

@@ -548,3 +548,131 @@ def test_shard_pack_unpack_reproduces_the_unsharded_step():
         for fp in ctxs:
             assert np.array_equal(fp.get_field(fid), want), fid
     assert sum(fp.stats()["grav_targets"] for fp in ctxs) == pr.n
+
+
+# ------------------------------------------------------------------------------------------------
+# pre-condition of the path: drift (predict.c:129-259) and box wrapping (predict.c:282-310)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("comoving", [False, True])
+def test_drift_parity(comoving):
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    rng = np.random.default_rng(21)
+    n, ng = pr.n, pr.ngas
+    ti_cur = rng.integers(0, 3, n).astype(np.int32)          # lazily drifted: mixed time0
+    grav = rng.standard_normal((n, 3))
+    hyd = rng.standard_normal((ng, 3))
+    dens = 1.0 + rng.random(ng)
+    divv = rng.standard_normal(ng)
+    pres = rng.random(ng)
+    hs = pr.hsml0[:ng] * (0.5 + rng.random(ng))
+    tabs = None
+    kw = {}
+    if comoving:
+        t = np.linspace(0.01, 1.0, 1000)
+        tabs = [np.cumsum(t ** 1.5) * 1e-3, np.cumsum(t ** 0.5) * 1e-3, np.cumsum(t ** 0.2) * 1e-3]
+        kw = dict(tables=tabs, log_time_begin=np.log(0.02), log_time_max=np.log(1.0))
+    fp = pr.device()
+    hfull = pr.hsml0.copy()
+    hfull[:ng] = hs
+    for fid, arr in ((B.F_TI_CURRENT, ti_cur), (B.F_GRAVACCEL, grav), (B.F_HYDROACCEL, hyd),
+                     (B.F_DENSITY, dens), (B.F_DIVVEL, divv), (B.F_PRESSURE, pres),
+                     (B.F_HSML, hfull)):
+        fp.set_field(fid, arr)
+    minh = float(np.median(hs))
+    fp.drift(7, pr.timebase * 50, min_gas_hsml=minh, box_wrap=True, boxsize=pr.box, **kw)
+    want = O.drift(7, pr.timebase * 50, pr.ic["pos"], pr.ic["vel"], pr.ic["type"], ti_cur,
+                   pr.timebin, pr.ti_begstep, grav, pr.velpred, hyd, dens, hs, divv, pr.entropy,
+                   pr.dtentropy, pres, minhsml=minh, wrap=True, boxsize=pr.box, **kw)
+    assert want["rc"] == 0
+    assert np.array_equal(fp.get_field(B.F_TI_CURRENT), want["ti_current"])
+    assert np.abs(fp.get_field(B.F_POS) - want["pos"]).max() < 1e-15
+    assert relerr(fp.get_field(B.F_VELPRED), want["velpred"]) < 1e-14
+    assert relerr(fp.get_field(B.F_DENSITY), want["density"]) < 1e-14
+    assert relerr(fp.get_field(B.F_HSML)[:ng], want["hsml"]) < 1e-14
+    assert relerr(fp.get_field(B.F_PRESSURE), want["pressure"]) < 1e-13
+    assert (fp.get_field(B.F_POS) >= 0).all() and (fp.get_field(B.F_POS) < pr.box).all()
+    # a particle ahead of the target time is the reference's endrun(12)
+    with pytest.raises(B.GhipError):
+        fp.drift(3, pr.timebase)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs at full size: size-independent properties (the oracle would take too long
+# for everything, so it checks a sample and the domain's invariants check the rest)
+# ------------------------------------------------------------------------------------------------
+def test_config_c1_32cubed_dm_only_tree_gravity():
+    """c1: 32^3 DM-only, tree gravity only: full oracle comparison is affordable."""
+    B = bindings()
+    pr = Problem(ng=32, gas=False, periodic=1, clustered=False)
+    fp = pr.device()
+    pr.device_tree(fp)
+    T = pr.oracle_tree()
+    tg = _all(pr.n)
+    tab = O.ewald_table(pr.box)
+    old = np.zeros(pr.n)
+    for theta in (pr.theta, 0.0):
+        fp.set_field(B.F_OLDACC, old)
+        fp.gravity(pr.g_grav(theta), B.WALK_NEWTON)
+        fp.gravity(pr.g_grav(theta), B.WALK_EWALD)
+        oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+        T.gravity_ewald_add(pr.o_grav(theta), tab, tg, old, oacc, ocost)
+        assert np.array_equal(fp.get_field(B.F_GRAVCOST), ocost)
+        assert relerr(fp.get_field(B.F_GRAVACCEL), oacc) < TOL
+        old = np.linalg.norm(oacc, axis=1)
+    assert fp.stats()["gastree_nodes"] == 0
+
+
+def test_config_c2_64cubed_full_step_properties():
+    """c2 (the benched workload): sampled oracle parity + invariants over all 524 288 particles."""
+    B = bindings()
+    pr = Problem(ng=64, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    fp = pr.device()
+    pr.device_tree(fp)
+    fp.set_field(B.F_OLDACC, np.zeros(n))
+    fp.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
+    fp.gravity(pr.g_grav(pr.theta), B.WALK_EWALD)
+    fp.gravity_finish(pr.G)
+    old = fp.get_field(B.F_OLDACC)
+    fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON)
+    fp.gravity(pr.g_grav(0.0), B.WALK_EWALD)
+    acc = fp.get_field(B.F_GRAVACCEL)
+    cost = fp.get_field(B.F_GRAVCOST)
+    st = fp.stats()
+    assert int(cost.sum()) == st["grav_interactions"] + st["ewald_interactions"]
+    # (i) sampled oracle parity of the relative-criterion pass
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(n, 2048, replace=False)).astype(np.int32)
+    T = pr.oracle_tree()
+    tab = O.ewald_table(pr.box)
+    oacc, ocost = T.gravity(pr.o_grav(0.0), sample, old)
+    T.gravity_ewald_add(pr.o_grav(0.0), tab, sample, old, oacc, ocost)
+    assert np.array_equal(cost[sample], ocost)
+    assert relerr(acc[sample], oacc) < TOL
+    # (ii) Newton's third law: the tree force nearly conserves total momentum
+    m = pr.ic["mass"]
+    ptot = (m[:, None] * acc).sum(axis=0)
+    assert np.abs(ptot).max() < 2e-3 * np.abs(m[:, None] * acc).sum(axis=0).max()
+    # (iii) accuracy vs direct summation + Ewald on a sample: inside the criterion's tolerance
+    d = O.gravity_direct(pr.ic["pos"], m, pr.ic["type"], pr.force_soft, sample[:256], periodic=1,
+                         boxsize=pr.box, ewald_tab=tab)
+    err = np.linalg.norm(acc[sample[:256]] - d, axis=1) / np.linalg.norm(d, axis=1)
+    assert np.percentile(err, 95) < 0.05 and np.median(err) < 0.02
+    # SPH: every gas particle ends inside the neighbour window, pairwise forces cancel
+    fp.density(pr.g_dens())
+    fp.update_hmax()
+    fp.hydro(pr.g_hydro())
+    nn = fp.get_field(B.F_NUMNGB)
+    assert np.all(np.abs(nn - pr.des_ngb) <= pr.max_dev + 1e-9)
+    assert np.all(fp.get_field(B.F_DENSITY) > 0)
+    ha = fp.get_field(B.F_HYDROACCEL)
+    mg = m[:ng]
+    ph = (mg[:, None] * ha).sum(axis=0)
+    assert np.abs(ph).max() < 1e-10 * np.abs(mg[:, None] * ha).sum()
+    # sampled oracle parity of density and hydro (neighbour sums need the full tree only)
+    act = sample[sample < ng][:512]
+    od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                   pr.ti_begstep, pr.hsml0)
+    assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
+    assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
