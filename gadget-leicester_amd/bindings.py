@@ -97,7 +97,7 @@ EXPORTS = [
     "ghip_update_hmax", "ghip_hydro", "ghip_density_evaluate", "ghip_ngb_treefind",
     "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
-    "ghip_drift"]
+    "ghip_drift", "ghip_gravity_finish_all"]
 
 
 def lib():
@@ -125,6 +125,7 @@ def lib():
         L.ghip_gravity_ext.argtypes = [vp, C.POINTER(GravParams), C.c_int, C.c_int, vp, vp, vp,
                                        vp, vp]
         L.ghip_gravity_finish.argtypes = [vp, C.c_double]
+        L.ghip_gravity_finish_all.argtypes = [vp, C.c_double]
         L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
         L.ghip_density.argtypes = [vp, C.POINTER(DensParams)]
         L.ghip_update_hmax.argtypes = [vp]
@@ -256,6 +257,9 @@ class ForcePath:
 
     def gravity_finish(self, G):
         self._chk(self.L.ghip_gravity_finish(self.h, float(G)))
+
+    def gravity_finish_all(self, G):
+        self._chk(self.L.ghip_gravity_finish_all(self.h, float(G)))
 
     def gravity_direct(self, params):
         self._chk(self.L.ghip_gravity_direct(self.h, C.byref(params)))

@@ -497,8 +497,11 @@ extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
 
 extern "C" int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks)
 {
-  if(!ctx || nranks < 1 || rank < 0 || rank >= nranks)
-    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_shard: need 0 <= rank < nranks");
+  if(!ctx || nranks < 1 || nranks > GHIP_MAXRANKS || rank < 0 || rank >= nranks)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_shard: need 0 <= rank < nranks <= %d",
+                     GHIP_MAXRANKS);
+  if(nranks != ctx->shard_n)
+    ctx->lists_dirty = true;   // the stored list order is rank-major
   ctx->shard_rank = rank;
   ctx->shard_n = nranks;
   return GHIP_OK;

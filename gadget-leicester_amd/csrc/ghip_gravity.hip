@@ -321,15 +321,8 @@ static void launch_walk_any(ghip_ctx *ctx, int walk, const TreeDev &t, const Wal
 
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
 {
-  int per = (nt + ctx->shard_n - 1) / ctx->shard_n;
-  int a = ctx->shard_rank * per;
-  int b = a + per;
-  if(a > nt)
-    a = nt;
-  if(b > nt)
-    b = nt;
-  *lo = a;
-  *cnt = b - a;
+  int per;
+  ghip_shard_range(nt, ctx->shard_n, ctx->shard_rank, lo, cnt, &per);
 }
 
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
@@ -476,6 +469,25 @@ extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
     return GHIP_OK;
   k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
     nt, P<int>(ctx->tg_grav) + lo, P<int>(ctx->gt.perm), ctx->n, G,
+    P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+// the same post-pass over EVERY active target regardless of the shard (after the all-gather of
+// the sharded walks each rank holds all G-less accelerations)
+extern "C" int ghip_gravity_finish_all(ghip_ctx *ctx, double G)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  if(!ctx->gt.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_finish_all: no tree");
+  GCHK(ghip_build_target_lists(ctx));
+  int nt = ctx->nt_grav;
+  if(nt == 0)
+    return GHIP_OK;
+  k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
+    nt, P<int>(ctx->tg_grav), P<int>(ctx->gt.perm), ctx->n, G,
     P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
   HIPCHK(hipGetLastError());
   return GHIP_OK;

@@ -31,6 +31,7 @@ struct TreeDev
   int n = 0;        // particles in this tree
   int nnodes = 0;
   int nelem = 0;    // n + nnodes
+  int maxlevel = GHIP_BITS;  // deepest node level
   // sort
   DevBuf key, skey, idx, perm, iperm;  // u64[n], u64[n], i32[n], i32[n] (sorted->host index), i32[nhost]
   DevBuf cpl, cnt, nb;                 // i32[n]: common prefix levels, node counts, exclusive scan
@@ -124,6 +125,34 @@ static inline int cdiv(long long a, int b) { return (int) ((a + b - 1) / b); }
 
 template <class T> static inline T *P(DevBuf &b) { return reinterpret_cast<T *>(b.p); }
 template <class T> static inline const T *P(const DevBuf &b) { return reinterpret_cast<const T *>(b.p); }
+
+// Target sharding (multi-GPU).  The curve-ordered target list is cut into buckets of 64; rank r
+// owns buckets r, r+N, r+2N, ... (every rank samples the whole volume, so per-rank cost is
+// balanced without a cost model).  The list is stored rank-major, so a rank's targets are the
+// contiguous range [lo, lo+cnt); `per` is the padded common slice length of the all-gathers.
+#define GHIP_MAXRANKS 64
+static inline void ghip_shard_range(int nt, int nranks, int rank, int *lo, int *cnt, int *per)
+{
+  int nb = (nt + 63) / 64;
+  int lastsize = nt - (nb - 1) * 64;
+  int acc = 0, mine = 0, mylo = 0;
+  for(int r = 0; r < nranks; r++)
+    {
+      int cb = (r < nb) ? (nb - r + nranks - 1) / nranks : 0;
+      int c = cb * 64;
+      if(cb > 0 && (nb - 1) % nranks == r)
+        c -= 64 - lastsize;
+      if(r == rank)
+        {
+          mylo = acc;
+          mine = c;
+        }
+      acc += c;
+    }
+  *lo = mylo;
+  *cnt = mine;
+  *per = ((nb + nranks - 1) / nranks) * 64;
+}
 
 // tree.hip
 int ghip_tree_build_impl(ghip_ctx *ctx);

@@ -1,4 +1,6 @@
 // ghip_shard.hip -- multi-GPU target sharding: pack / unpack of per-target results.
+// (slice layout: ghip_shard_range in ghip_internal.h -- buckets of 64 curve-consecutive targets
+// dealt round-robin to the ranks)
 //
 // Replaces the reference's MPI export rounds (gravtree.c:175-339, density.c:193-389,
 // hydra.c:274-526: "export targets that touched a pseudo-particle, walk remotely, send partial
@@ -18,16 +20,13 @@ static const int kWidth[3] = {4, 7, 5};
 
 static void slice_of(int nt, int nranks, int rank, int *per, int *lo, int *cnt)
 {
-  int p = (nt + nranks - 1) / nranks;
-  int a = rank * p, b = a + p;
-  if(a > nt)
-    a = nt;
-  if(b > nt)
-    b = nt;
-  *per = p;
-  *lo = a;
-  *cnt = b - a;
+  ghip_shard_range(nt, nranks, rank, lo, cnt, per);
 }
+
+struct ShardLo
+{
+  int lo[GHIP_MAXRANKS + 1];
+};
 
 extern "C" int ghip_shard_count(ghip_ctx *ctx, int gas, int *per, int *mine)
 {
@@ -77,7 +76,8 @@ __global__ void k_shard_pack(int group, int cnt, int per, const int *__restrict_
     }
 }
 
-__global__ void k_shard_unpack(int group, int nt, int per, int width, int skip_rank,
+__global__ void k_shard_unpack(int group, int nt, int per, int width, int skip_rank, int nranks,
+                               ShardLo L,
                                const int *__restrict__ tgt, const int *__restrict__ perm, int n,
                                int ngas, const double *__restrict__ buf, double *__restrict__ f0,
                                double *__restrict__ f1, double *__restrict__ f2,
@@ -89,7 +89,10 @@ __global__ void k_shard_unpack(int group, int nt, int per, int width, int skip_r
   int ti = blockIdx.x * blockDim.x + threadIdx.x;
   if(ti >= nt)
     return;
-  int r = ti / per, a = ti - r * per;
+  int r = 0;
+  while(r + 1 < nranks && ti >= L.lo[r + 1])
+    r++;
+  int a = ti - L.lo[r];
   if(r == skip_rank)
     return;  // own slice is already in place
   const double *b = buf + (size_t) r * width * per;
@@ -203,8 +206,19 @@ extern "C" int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_a
       f[1] = P<double>(ctx->f[GHIP_F_DTENTROPY]);
       f[2] = P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]);
     }
+  ShardLo L;
+  for(int r = 0; r <= ctx->shard_n && r <= GHIP_MAXRANKS; r++)
+    {
+      int l, c, p2;
+      if(r < ctx->shard_n)
+        ghip_shard_range(nt, ctx->shard_n, r, &l, &c, &p2);
+      else
+        l = nt;
+      L.lo[r] = l;
+    }
   k_shard_unpack<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
-    group, nt, per, kWidth[group], ctx->shard_rank, P<int>(gas ? ctx->tg_gas : ctx->tg_grav),
+    group, nt, per, kWidth[group], ctx->shard_rank, ctx->shard_n, L,
+    P<int>(gas ? ctx->tg_gas : ctx->tg_grav),
     P<int>(t.perm), ctx->n, ctx->ngas, (const double *) dev_buf_all, f[0], f[1], f[2], f[3], f[4],
     f[5], f[6], P<int>(ctx->f[GHIP_F_GRAVCOST]), P<double>(ctx->gp), P<double>(ctx->gq));
   HIPCHK(hipGetLastError());

@@ -325,15 +325,8 @@ __global__ void k_dens_finalize(int nt, const int *__restrict__ tgt, const int *
 
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
 {
-  int per = (nt + ctx->shard_n - 1) / ctx->shard_n;
-  int a = ctx->shard_rank * per;
-  int b = a + per;
-  if(a > nt)
-    a = nt;
-  if(b > nt)
-    b = nt;
-  *lo = a;
-  *cnt = b - a;
+  int per;
+  ghip_shard_range(nt, ctx->shard_n, ctx->shard_rank, lo, cnt, &per);
 }
 
 static int dens_alloc(ghip_ctx *ctx)

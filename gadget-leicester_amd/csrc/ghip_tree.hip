@@ -208,12 +208,23 @@ __device__ __forceinline__ int d_common_levels(unsigned long long a, unsigned lo
 }
 
 __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ skey,
-                                int *__restrict__ cpl)
+                                int *__restrict__ cpl, int *__restrict__ maxlevel)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  cpl[i] = (i + 1 < n) ? d_common_levels(skey[i], skey[i + 1]) : -1;
+  int c = -1;
+  if(i < n)
+    {
+      c = (i + 1 < n) ? d_common_levels(skey[i], skey[i + 1]) : -1;
+      cpl[i] = c;
+    }
+  // deepest node level of the tree = largest shared-digit count (one atomic per wavefront)
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      int o = __shfl_xor(c, off, 64);
+      c = o > c ? o : c;
+    }
+  if((threadIdx.x & 63) == 0 && c >= 0)
+    atomicMax(maxlevel, c);
 }
 
 __global__ void k_node_counts(int n, const int *__restrict__ cpl, int *__restrict__ cnt)
@@ -539,19 +550,25 @@ static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const do
                                             P<unsigned long long>(t.skey), P<int>(t.idx),
                                             P<int>(t.perm), n, 0, 63, st));
 
-  k_prefix_levels<<<cdiv(n, 256), 256, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl));
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  int *dmaxlev = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 48);
+  HIPCHK(hipMemsetAsync(dmaxlev, 0, 4, st));
+  k_prefix_levels<<<cdiv(n, 256), 256, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl),
+                                                dmaxlev);
   k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), P<int>(t.cnt));
   HIPCHK(hipGetLastError());
   tb = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
   GCHK(cub_tmp(ctx, tb));
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
-  int last_nb = 0, last_cnt = 0;
+  int last_nb = 0, last_cnt = 0, maxlev = 0;
+  HIPCHK(hipMemcpyAsync(&maxlev, dmaxlev, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&last_nb, P<int>(t.nb) + (n - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&last_cnt, P<int>(t.cnt) + (n - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   t.nnodes = last_nb + last_cnt;
   t.nelem = n + t.nnodes;
+  t.maxlevel = maxlev < GHIP_BITS ? maxlev : GHIP_BITS;
 
   GCHK(ghip_ensure(ctx, t.xm, (size_t) t.nelem * sizeof(double4)));
   GCHK(ghip_ensure(ctx, t.cl, (size_t) t.nelem * sizeof(double4)));
@@ -574,7 +591,7 @@ static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const do
     P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
   HIPCHK(hipGetLastError());
 
-  for(int L = GHIP_BITS; L >= 0; L--)
+  for(int L = t.maxlevel; L >= 0; L--)
     {
       if(grav)
         k_node_level<true, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
@@ -703,7 +720,7 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
   HIPCHK(hipEventRecord(ctx->ev[8], st));
   k_aux_from_gp<<<cdiv(t.nelem, 256), 256, 0, st>>>(t.nelem, P<int4>(t.lk), P<double>(ctx->gp),
                                                    P<double>(t.aux));
-  for(int L = GHIP_BITS; L >= 0; L--)
+  for(int L = t.maxlevel; L >= 0; L--)
     k_node_level<false, false><<<cdiv(t.nelem, 256), 256, 0, st>>>(
       t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
   HIPCHK(hipGetLastError());
@@ -752,12 +769,55 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
   return GHIP_OK;
 }
 
+struct ShardLoT
+{
+  int lo[GHIP_MAXRANKS + 1];
+};
+
+// curve order -> rank-major order: position j of rank r's slice holds bucket (j/64)*N + r
+__global__ void k_shard_permute(int nt, int nranks, ShardLoT L, const int *__restrict__ src,
+                                int *__restrict__ dst)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if(j >= nt)
+    return;
+  int r = 0;
+  while(r + 1 < nranks && j >= L.lo[r + 1])
+    r++;
+  int a = j - L.lo[r];
+  int gb = (a >> 6) * nranks + r;
+  dst[j] = src[gb * 64 + (a & 63)];
+}
+
+static int permute_for_shards(ghip_ctx *ctx, DevBuf &list, int nt)
+{
+  if(ctx->shard_n <= 1 || nt == 0)
+    return GHIP_OK;
+  ShardLoT L;
+  for(int r = 0; r <= ctx->shard_n; r++)
+    {
+      int l = nt, c, p2;
+      if(r < ctx->shard_n)
+        ghip_shard_range(nt, ctx->shard_n, r, &l, &c, &p2);
+      L.lo[r] = l;
+    }
+  GCHK(ghip_ensure(ctx, ctx->dtgt_b, (size_t) nt * 4 + 16));
+  HIPCHK(hipMemcpyAsync(ctx->dtgt_b.p, list.p, (size_t) nt * 4, hipMemcpyDeviceToDevice,
+                        ctx->stream));
+  k_shard_permute<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(nt, ctx->shard_n, L,
+                                                          P<int>(ctx->dtgt_b), P<int>(list));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
 int ghip_build_target_lists(ghip_ctx *ctx)
 {
   if(!ctx->lists_dirty)
     return GHIP_OK;
   GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
   GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
+  GCHK(permute_for_shards(ctx, ctx->tg_grav, ctx->nt_grav));
+  GCHK(permute_for_shards(ctx, ctx->tg_gas, ctx->nt_gas));
   ctx->lists_dirty = false;
   return GHIP_OK;
 }

@@ -63,9 +63,12 @@ class ShardedForceStep:
         for w in walks:
             e.gravity(grav_params, w)
         self.exchange(GROUP_GRAVITY)
-        e.set_shard(0, 1)              # OldAcc / G scaling for every particle, on every rank
-        e.gravity_finish(G)
-        e.set_shard(self.rank, self.world)
+        if hasattr(e, "gravity_finish_all"):
+            e.gravity_finish_all(G)    # OldAcc / G scaling for every particle, on every rank
+        else:
+            e.set_shard(0, 1)
+            e.gravity_finish(G)
+            e.set_shard(self.rank, self.world)
         if has_gas:
             e.density(dens_params)
             self.exchange(GROUP_DENSITY)

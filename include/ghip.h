@@ -208,6 +208,8 @@ int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
                      int *ninteractions);
 /* OldAcc = |GravAccel| and GravAccel *= G for the active particles (gravtree.c:381-403) */
 int ghip_gravity_finish(ghip_ctx *ctx, double G);
+/* the same for ALL active particles regardless of the shard (multi-GPU: after the all-gather) */
+int ghip_gravity_finish_all(ghip_ctx *ctx, double G);
 /* softened direct summation over all particles for the active targets (accuracy oracle on
  * device, formula of forcetree.c:4273-4336); writes GRAVACCEL */
 int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p);
