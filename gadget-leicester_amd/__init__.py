@@ -39,7 +39,8 @@ def hipcc_path():
 def build(force=False, verbose=False):
     """Compile libghip.so (HIP, gfx950) and libgadget_force.so (host C mirror) in-tree."""
     hipcc = hipcc_path()
-    hdrs = [os.path.join(CSRC, "ghip_internal.h"), os.path.join(REPO_DIR, "include", "ghip.h")]
+    hdrs = [os.path.join(CSRC, "ghip_internal.h"), os.path.join(CSRC, "ghip_walk.h"),
+            os.path.join(REPO_DIR, "include", "ghip.h")]
     objs = []
     procs = []
     for src in HIP_SOURCES:

@@ -6,6 +6,8 @@
 // the OldAcc / G post-pass (gravtree.c:381-403) and ewald_init() (forcetree.c:4402-4527).
 #include <cmath>
 
+#include <hipcub/hipcub.hpp>
+
 #include "ghip_walk.h"
 
 // gravtree.c:381-403: OldAcc = |GravAccel| (G-less), then GravAccel *= G
@@ -82,6 +84,21 @@ k_grav_direct(int n, const double *__restrict__ sx, const double *__restrict__ s
       ay[ti] = a1;
       az[ti] = a2;
     }
+}
+
+__global__ void k_scatter_direct(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
+                                 const double *__restrict__ ax, const double *__restrict__ ay,
+                                 const double *__restrict__ az, int n, double *__restrict__ oacc,
+                                 int *__restrict__ ocost)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  int i = perm[tgt[ti]];
+  oacc[i] = ax[ti];
+  oacc[(size_t) n + i] = ay[ti];
+  oacc[2 * (size_t) n + i] = az[ti];
+  ocost[i] = 0;
 }
 
 __global__ void k_pack_xyzm(int n, const double *__restrict__ x, const double *__restrict__ y,
@@ -221,21 +238,37 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
 }
 
 // segment table of the gravity tree; called at the end of every tree build
-int ghip_build_segments(ghip_ctx *ctx, TreeDev &t)
+int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
 {
+  const bool gas_tree = !walk_records;
   t.ns = 1;
   if(t.n == 0)
     return GHIP_OK;
-  int ns = t.nelem / 4096;      // >= 4096 elements per segment, at most 64 segments
+  // >= 2048 elements per segment, at most 256 segments: the segment is the unit of work a
+  // wavefront cannot split, and a bucket spends most of its steps in the one or two segments that
+  // hold its own neighbourhood (measured at c2: 64 -> 256 segments: 12.2 -> 10.8 ms)
+  int ns = t.nelem / 2048;
   if(ns < 1)
     ns = 1;
-  if(ns > 64)
-    ns = 64;
+  if(ns > 256)
+    ns = 256;
   if(getenv("GHIP_WALK_SEGMENTS"))
     {
       int v = atoi(getenv("GHIP_WALK_SEGMENTS"));
       if(v >= 1 && v <= 4096)
         ns = v;
+    }
+  if(gas_tree)
+    {
+      // the SPH walks touch 1-2 of 64 segments per bucket, so splitting them only adds ancestor
+      // replays (measured: density +50 %, hydro +60 % at c2); kept switchable for experiments
+      ns = 1;
+      if(getenv("GHIP_SPH_SEGMENTS"))
+        {
+          int v = atoi(getenv("GHIP_SPH_SEGMENTS"));
+          if(v >= 1 && v <= 4096)
+            ns = v;
+        }
     }
   t.ns = ns;
   GCHK(ghip_ensure(ctx, t.seg_start, (size_t) (ns + 1) * 4));
@@ -243,6 +276,9 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t)
   GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) ns * GHIP_MAXANC * 4));
   k_build_segments<<<cdiv(ns + 1, 64), 64, 0, ctx->stream>>>(
     t.nelem, P<int4>(t.lk), ns, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
+  HIPCHK(hipGetLastError());
+  if(!walk_records)
+    return GHIP_OK;
   GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkHot)));
   GCHK(ghip_ensure(ctx, t.mq2, (size_t) (t.nelem + 1) * sizeof(WalkCold)));
   k_fill_elems<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double4>(t.xm),
@@ -253,7 +289,7 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t)
   return GHIP_OK;
 }
 
-static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg)
 {
   sg.ns = t.ns;
   sg.nsub = t.ns < GHIP_MAXSUB ? t.ns : GHIP_MAXSUB;
@@ -268,13 +304,18 @@ static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
   sg.start = P<int>(t.seg_start);
   sg.nanc = P<int>(t.seg_nanc);
   sg.anc = P<int>(t.seg_anc);
-  *nbuckets = (nt + 63) / 64;
   return sg.nsub;
 }
 
-static int ensure_partials(ghip_ctx *ctx, int nt, int nsub)
+static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
 {
-  size_t cnt = (size_t) nt * nsub;
+  *nbuckets = (nt + 63) / 64;
+  return ghip_walk_layout(t, sg);
+}
+
+static int ensure_partials(ghip_ctx *ctx, int nwaves)
+{
+  size_t cnt = (size_t) nwaves * 64;
   GCHK(ghip_ensure(ctx, ctx->tax, cnt * 8));
   GCHK(ghip_ensure(ctx, ctx->tay, cnt * 8));
   GCHK(ghip_ensure(ctx, ctx->taz, cnt * 8));
@@ -282,41 +323,111 @@ static int ensure_partials(ghip_ctx *ctx, int nt, int nsub)
   return GHIP_OK;
 }
 
+// wavefront plan of one walk call (see k_plan_nsub): kind 0 Newton/short-range, 1 Ewald,
+// 2 external targets (never has history)
+static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan)
+{
+  hipStream_t st = ctx->stream;
+  int sbase = (49152 + nb - 1) / nb;
+  sbase = sbase < 8 ? 8 : (sbase > 64 ? 64 : sbase);
+  if(sbase > ns)
+    sbase = ns;
+  if(getenv("GHIP_WALK_SUBS"))
+    {
+      int v = atoi(getenv("GHIP_WALK_SUBS"));
+      if(v >= 1 && v <= ns)
+        sbase = v;
+    }
+  const int maxwaves = (sbase + 2) * nb + 8;
+  GCHK(ghip_ensure(ctx, ctx->plan_nsub, (size_t) nb * 4));
+  GCHK(ghip_ensure(ctx, ctx->plan_woff, (size_t) (nb + 1) * 4));
+  GCHK(ghip_ensure(ctx, ctx->plan_wave, (size_t) maxwaves * 4));
+  GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][0], (size_t) nb * 4));
+  GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][1], (size_t) nb * 4));
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  const bool adaptive = !(getenv("GHIP_WALK_ADAPTIVE") && atoi(getenv("GHIP_WALK_ADAPTIVE")) == 0);
+  int have_prev = (adaptive && kind < 2 && ctx->plan_nb[kind] == nb && ctx->plan_ns[kind] == ns) ? 1 : 0;
+  int cur = ctx->plan_cur[kind];
+  unsigned int *prev = P<unsigned int>(ctx->plan_steps[kind][cur]);
+  unsigned int *out = P<unsigned int>(ctx->plan_steps[kind][cur ^ 1]);
+  // total of the previous call of this kind (the walk accumulates it in counters[8 + kind]);
+  // saved before the caller clears the counter
+  unsigned long long *total_prev = P<unsigned long long>(ctx->counters) + 56 + kind;
+  if(have_prev)
+    HIPCHK(hipMemcpyAsync(total_prev, P<unsigned long long>(ctx->counters) + 8 + kind, 8,
+                          hipMemcpyDeviceToDevice, st));
+  k_plan_nsub<<<cdiv(nb, 256), 256, 0, st>>>(nb, ns, sbase, prev, total_prev, have_prev,
+                                             P<int>(ctx->plan_nsub));
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(ctx->plan_nsub),
+                                          P<int>(ctx->plan_woff), nb, st));
+  GCHK(ghip_ensure(ctx, ctx->cubtmp, tb + 256));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, P<int>(ctx->plan_nsub),
+                                          P<int>(ctx->plan_woff), nb, st));
+  HIPCHK(hipMemsetAsync(ctx->plan_wave.p, 0xff, (size_t) maxwaves * 4, st));
+  k_plan_fill<<<cdiv(nb, 256), 256, 0, st>>>(nb, P<int>(ctx->plan_nsub), P<int>(ctx->plan_woff),
+                                             maxwaves, P<int>(ctx->plan_wave), out);
+  HIPCHK(hipGetLastError());
+  if(kind < 2)
+    {
+      ctx->plan_nb[kind] = nb;
+      ctx->plan_ns[kind] = ns;
+      ctx->plan_cur[kind] = cur ^ 1;
+    }
+  plan.nwaves = maxwaves;
+  plan.wave_bucket = P<int>(ctx->plan_wave);
+  plan.woff = P<int>(ctx->plan_woff);
+  plan.nsub = P<int>(ctx->plan_nsub);
+  plan.steps_out = out;
+  return GHIP_OK;
+}
+
 template <int MODE>
 static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int nbuckets, int nt,
                         const int *tgt, const double *tx, const double *ty, const double *tz,
                         const double *tsoft, const double *toldacc, const GravK &k,
-                        unsigned long long *counter)
+                        unsigned long long *counter, const WalkPlan &plan)
 {
-  long long nthreads = (long long) nbuckets * sg.nsub * 64;
-  int blocks = cdiv(nthreads, GHIP_BLOCK);
+  (void) nbuckets;
+  long long nthreads = (long long) plan.nwaves * 64;
+  // one wavefront per workgroup: wavefronts of a bucket finish at very different times, and a
+  // 256-thread workgroup would hold its four slots until the slowest one is done
+  int bsize = GHIP_BLOCK;
+  if(getenv("GHIP_WALK_BLOCK"))
+    {
+      int v = atoi(getenv("GHIP_WALK_BLOCK"));
+      if(v == 64 || v == 128 || v == 256)
+        bsize = v;
+    }
+  int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
   if(k.periodic)
-    k_grav_walk<MODE, true><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
+    k_grav_walk<MODE, true><<<blocks, bsize, 0, ctx->stream>>>(
       t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
       P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
-      P<double>(ctx->taz), P<int>(ctx->tcost), counter);
+      P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan);
   else
-    k_grav_walk<MODE, false><<<blocks, GHIP_BLOCK, 0, ctx->stream>>>(
+    k_grav_walk<MODE, false><<<blocks, bsize, 0, ctx->stream>>>(
       t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
       P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
-      P<double>(ctx->taz), P<int>(ctx->tcost), counter);
+      P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan);
 }
 
 static void launch_walk_any(ghip_ctx *ctx, int walk, const TreeDev &t, const WalkSeg &sg,
                             int nbuckets, int nt, const int *tgt, const double *tx,
                             const double *ty, const double *tz, const double *tsoft,
-                            const double *toldacc, const GravK &k, unsigned long long *counter)
+                            const double *toldacc, const GravK &k, unsigned long long *counter,
+                            const WalkPlan &plan)
 {
   if(walk == GHIP_WALK_NEWTON)
     launch_walk<GHIP_WALK_NEWTON>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                  counter);
+                                  counter, plan);
   else if(walk == GHIP_WALK_SHORTRANGE)
     launch_walk<GHIP_WALK_SHORTRANGE>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                      counter);
+                                      counter, plan);
   else
     launch_walk<GHIP_WALK_EWALD>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                 counter);
+                                 counter, plan);
 }
 
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
@@ -351,9 +462,10 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   const int *tgt = P<int>(ctx->tg_grav) + lo;
   WalkSeg sg;
   int nbuckets;
-  int nsub = walk_layout(ctx->gt, nt, sg, &nbuckets);
-  GCHK(ensure_partials(ctx, nt, nsub));
-  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  walk_layout(ctx->gt, nt, sg, &nbuckets);
+  WalkPlan plan;
+  GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, nbuckets, sg.ns, plan));
+  GCHK(ensure_partials(ctx, plan.nwaves));
   unsigned long long *counter =
     P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
@@ -367,12 +479,12 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   HIPCHK(hipEventRecord(ctx->ev[evi], st));
   launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, tgt, P<double>(ctx->sx),
                   P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
-                  P<double>(ctx->soldacc), k, counter);
+                  P<double>(ctx->soldacc), k, counter, plan);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[evi + 1], st));
 
   k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
-    nt, nsub, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
+    nt, plan, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
     P<double>(ctx->taz), P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
     P<int>(ctx->f[GHIP_F_GRAVCOST]), walk == GHIP_WALK_EWALD ? 1 : 0, k.debug_steps);
   HIPCHK(hipGetLastError());
@@ -433,13 +545,14 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
                                                   p->ForceSoftening[5], dsoft);
   WalkSeg sg;
   int nbuckets;
-  int nsub = walk_layout(ctx->gt, nt, sg, &nbuckets);
-  GCHK(ensure_partials(ctx, nt, nsub));
-  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  walk_layout(ctx->gt, nt, sg, &nbuckets);
+  WalkPlan plan;
+  GCHK(build_plan(ctx, 2, nbuckets, sg.ns, plan));
+  GCHK(ensure_partials(ctx, plan.nwaves));
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 2;
   launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
-                  counter);
-  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, nsub, nullptr, nullptr, P<double>(ctx->tax),
+                  counter, plan);
+  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, plan, nullptr, nullptr, P<double>(ctx->tax),
                                                P<double>(ctx->tay), P<double>(ctx->taz),
                                                P<int>(ctx->tcost), nt, dacc, dcost, 0, 0);
   HIPCHK(hipGetLastError());
@@ -524,10 +637,9 @@ extern "C" int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p)
                                                P<double>(ctx->tax), P<double>(ctx->tay),
                                                P<double>(ctx->taz));
   HIPCHK(hipMemsetAsync(ctx->tcost.p, 0, (size_t) nt * 4, st));
-  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
-    nt, 1, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
-    P<double>(ctx->taz), P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
-    P<int>(ctx->f[GHIP_F_GRAVCOST]), 0, 0);
+  k_scatter_direct<<<cdiv(nt, 256), 256, 0, st>>>(
+    nt, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay), P<double>(ctx->taz),
+    n, P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<int>(ctx->f[GHIP_F_GRAVCOST]));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }

@@ -71,7 +71,8 @@ struct ghip_ctx
   DevBuf gp;  // 8 doubles: x,y,z,m,vx,vy,vz,h
   DevBuf gq;  // 8 doubles: pressure, density, dhsmlfac, divvel, curlvel, timestep, 0, 0
   // density work arrays (gas-tree order)
-  DevBuf dleft, dright, drho, dnumngb, ddhsml, ddivv, drot, dflags, dtgt_a, dtgt_b;
+  DevBuf dleft, dright, drho, dnumngb, ddhsml, ddivv, drot, dflags, dtgt_a, dtgt_b, dhcur;
+  DevBuf hpart;  // hydro partial sums
 
   // active lists
   DevBuf act_host_idx;  // i32[nactive] host indices (uploaded)
@@ -83,6 +84,10 @@ struct ghip_ctx
 
   // walk outputs in target order
   DevBuf tax, tay, taz, tcost;
+  // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
+  // visited per bucket in the previous call (double-buffered) and the scratch plan arrays
+  DevBuf plan_steps[3][2], plan_nsub, plan_woff, plan_wave;
+  int plan_nb[3] = {-1, -1, -1}, plan_ns[3] = {-1, -1, -1}, plan_cur[3] = {0, 0, 0};
 
   // ewald
   DevBuf ewtab;   // double4[(EN+1)^3]: fx,fy,fz,0 scaled by 1/Box^2
@@ -161,14 +166,43 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx);
 int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst);
 // gravity.hip
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
-int ghip_build_segments(ghip_ctx *ctx, TreeDev &t);
+int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records);
 // sph.hip
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p);
 
 // ---------------------------------------------------------------------------------------------
+// walk segments: the element list of a tree is cut into `ns` contiguous segments and `nsub`
+// wavefronts share one bucket of 64 targets (wavefront `sub` takes segments sub, sub+nsub, ...);
+// see ghip_walk.h "Load balance"
+// ---------------------------------------------------------------------------------------------
+#define GHIP_MAXANC 24
+#define GHIP_MAXSUB 8
+struct WalkSeg
+{
+  int ns;                          // number of segments
+  int nsub;                        // wavefronts per bucket
+  const int *__restrict__ start;   // [ns+1] first element of each segment
+  const int *__restrict__ nanc;    // [ns]
+  const int *__restrict__ anc;     // [ns][GHIP_MAXANC] ancestors of start[k], root first
+};
+
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg);   // returns nsub
+
+// ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_wave_min_i32(int v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      int o = __shfl_xor(v, off, 64);
+      v = o < v ? o : v;
+    }
+  return v;
+}
+
+
 // element link record: x = skip (element index after this subtree), y = sorted particle index
 // for a particle element or -(level+1) for a node, z = first particle of the node, w = count
 #define LK_IS_PARTICLE(lk) ((lk).y >= 0)

@@ -117,17 +117,45 @@ __device__ __forceinline__ void d_density_pair(const double *__restrict__ gp, in
     }
 }
 
-// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 targets per wave
+// first element of segment kseg that the wave still has to look at: replays the node test at the
+// segment's ancestors (outermost first); the first ancestor NO lane overlaps prunes everything up
+// to its skip index
+template <class LaneTest>
+__device__ __forceinline__ int d_sph_segment_entry(int kseg, const WalkSeg &sg,
+                                                  const double4 *__restrict__ cl,
+                                                  const int4 *__restrict__ lk, LaneTest test)
+{
+  int e = sg.start[kseg];
+  const int na = sg.nanc[kseg];
+  for(int a = 0; a < na; a++)
+    {
+      int ea = __builtin_amdgcn_readfirstlane(sg.anc[kseg * GHIP_MAXANC + a]);
+      if(!__any(test(ea, cl[ea])))
+        {
+          int sk = lk[ea].x;
+          return sk > e ? sk : e;
+        }
+    }
+  return e;
+}
+
+// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 targets; `nsub` wavefronts
+// share the bucket, each walking every nsub-th segment of the gas tree's element list.  Partial
+// sums go to [sub][nt] planes (summed in fixed order by k_dens_finalize).
 __global__ void __launch_bounds__(GHIP_BLOCK)
 k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-          const double *__restrict__ gp, int nt, const int *__restrict__ tgt,
-          const double *__restrict__ hcur, BoxK b, double *__restrict__ orho,
-          double *__restrict__ onum, double *__restrict__ odh, double *__restrict__ odiv,
-          double *__restrict__ orot, int ngas, unsigned long long *__restrict__ counter)
+          const double *__restrict__ gp, WalkSeg sg, int nt, const int *__restrict__ tgt,
+          const double *__restrict__ hcur, BoxK b, double *__restrict__ prho,
+          double *__restrict__ pnum, double *__restrict__ pdh, double *__restrict__ pdiv,
+          double *__restrict__ prot, unsigned long long *__restrict__ counter)
 {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int ti = wave * 64 + lane;
+  const int bucket = wave / sg.nsub;
+  const int sub = wave - bucket * sg.nsub;
+  if(bucket * 64 >= nt)
+    return;
+  const int ti = bucket * 64 + lane;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
   double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, h = 1;
@@ -145,46 +173,55 @@ k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk
   const double h2 = h * h, hinv = 1.0 / h;
   const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv;
   DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto test = [&](int, const double4 c) { return valid && d_node_overlaps(c, h, px, py, pz, b); };
 
-  int e = 0;
-  while(e < nelem)
+  for(int kseg = sub; kseg < sg.ns; kseg += sg.nsub)
     {
-      e = __builtin_amdgcn_readfirstlane(e);
-      const int4 k = lk[e];
-      if(LK_IS_PARTICLE(k))
+      const int s1 = sg.start[kseg + 1];
+      int e = d_sph_segment_entry(kseg, sg, cl, lk, test);
+      while(e < s1)
         {
-          d_density_pair(gp, k.y, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
-          e = e + 1;
-        }
-      else
-        {
-          const double4 c = cl[e];
-          bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
-          if(__any(open))
+          e = __builtin_amdgcn_readfirstlane(e);
+          const int4 k = lk[e];
+          if(LK_IS_PARTICLE(k))
             {
-              if(k.w <= LEAF_DIRECT)
-                {
-                  for(int j = k.z; j < k.z + k.w; j++)
-                    d_density_pair(gp, j, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b,
-                                   A);
-                  e = k.x;
-                }
-              else
-                e = e + 1;
+              d_density_pair(gp, k.y, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+              e = e + 1;
             }
           else
-            e = k.x;
+            {
+              const double4 c = cl[e];
+              bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
+              if(__any(open))
+                {
+                  // flat sweep only if the whole subtree lies inside this segment (its
+                  // particles are owned by the segments their elements fall in)
+                  if(k.w <= LEAF_DIRECT && k.x <= s1)
+                    {
+                      for(int j = k.z; j < k.z + k.w; j++)
+                        d_density_pair(gp, j, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4,
+                                       b, A);
+                      e = k.x;
+                    }
+                  else
+                    e = e + 1;
+                }
+              else
+                e = k.x;
+            }
         }
     }
   if(valid)
     {
-      orho[s] = A.rho;
-      onum[s] = A.wnum;
-      odh[s] = A.dhsml;
-      odiv[s] = A.divv;
-      orot[s] = A.rx;
-      orot[(size_t) ngas + s] = A.ry;
-      orot[2 * (size_t) ngas + s] = A.rz;
+      const size_t o = (size_t) sub * nt + ti;
+      const size_t plane = (size_t) sg.nsub * nt;
+      prho[o] = A.rho;
+      pnum[o] = A.wnum;
+      pdh[o] = A.dhsml;
+      pdiv[o] = A.divv;
+      prot[o] = A.rx;
+      prot[plane + o] = A.ry;
+      prot[2 * plane + o] = A.rz;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.nn);
   if(lane == 0 && tot)
@@ -212,8 +249,9 @@ struct DensFin
 };
 
 // finalisation + smoothing-length update, density.c:434-652, one thread per evaluated target
-__global__ void k_dens_finalize(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
-                                int n, int ngas, DensFin P, const double *__restrict__ srho,
+__global__ void k_dens_finalize(int nt, int nsub, const int *__restrict__ tgt,
+                                const int *__restrict__ perm, int n, int ngas, DensFin P,
+                                const double *__restrict__ srho,
                                 const double *__restrict__ snum, const double *__restrict__ sdh,
                                 const double *__restrict__ sdiv, const double *__restrict__ srot,
                                 double *__restrict__ hcur, double *__restrict__ left,
@@ -232,8 +270,19 @@ __global__ void k_dens_finalize(int nt, const int *__restrict__ tgt, const int *
   const int s = tgt[ti];
   const int i = perm[s];
   double h = hcur[s];
-  double rho = srho[s], numngb = snum[s], dhf = sdh[s], divv = sdiv[s];
-  double r0 = srot[s], r1 = srot[(size_t) ngas + s], r2 = srot[2 * (size_t) ngas + s];
+  double rho = 0, numngb = 0, dhf = 0, divv = 0, r0 = 0, r1 = 0, r2 = 0;
+  const size_t plane = (size_t) nsub * nt;
+  for(int q = 0; q < nsub; q++)   // fixed order: deterministic
+    {
+      const size_t o = (size_t) q * nt + ti;
+      rho += srho[o];
+      numngb += snum[o];
+      dhf += sdh[o];
+      divv += sdiv[o];
+      r0 += srot[o];
+      r1 += srot[plane + o];
+      r2 += srot[2 * plane + o];
+    }
   double curl = 0;
   if(rho > 0)
     {
@@ -334,11 +383,16 @@ static int dens_alloc(ghip_ctx *ctx)
   size_t ng = (size_t) (ctx->ngas > 0 ? ctx->ngas : 1);
   GCHK(ghip_ensure(ctx, ctx->dleft, ng * 8));
   GCHK(ghip_ensure(ctx, ctx->dright, ng * 8));
-  GCHK(ghip_ensure(ctx, ctx->drho, ng * 8));     // doubles as hcur? no: separate below
-  GCHK(ghip_ensure(ctx, ctx->dnumngb, ng * 8));
-  GCHK(ghip_ensure(ctx, ctx->ddhsml, ng * 8 * 2));  // dhsml sums + hcur
-  GCHK(ghip_ensure(ctx, ctx->ddivv, ng * 8));
-  GCHK(ghip_ensure(ctx, ctx->drot, ng * 8 * 3));
+  // per-wavefront partial sums: [nsub][targets] planes
+  size_t np_ = ng * GHIP_MAXSUB;
+  if(getenv("GHIP_WALK_SUBS"))
+    np_ = ng * 64;
+  GCHK(ghip_ensure(ctx, ctx->drho, np_ * 8));
+  GCHK(ghip_ensure(ctx, ctx->dnumngb, np_ * 8));
+  GCHK(ghip_ensure(ctx, ctx->ddhsml, np_ * 8));
+  GCHK(ghip_ensure(ctx, ctx->ddivv, np_ * 8));
+  GCHK(ghip_ensure(ctx, ctx->drot, np_ * 8 * 3));
+  GCHK(ghip_ensure(ctx, ctx->dhcur, ng * 8));
   GCHK(ghip_ensure(ctx, ctx->dflags, ng * 4));
   GCHK(ghip_ensure(ctx, ctx->dtgt_a, ng * 4 + 16));
   GCHK(ghip_ensure(ctx, ctx->dtgt_b, ng * 4 + 16));
@@ -363,7 +417,9 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   hipStream_t st = ctx->stream;
   TreeDev &t = ctx->st;
   GCHK(dens_alloc(ctx));
-  double *hcur = P<double>(ctx->ddhsml) + ng;
+  double *hcur = P<double>(ctx->dhcur);
+  WalkSeg sg;
+  const int nsub = ghip_walk_layout(t, sg);
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 4;
   int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
@@ -385,12 +441,12 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 
   while(ncur > 0)
     {
-      k_density<<<cdiv(ncur, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
-        t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), ncur, cur, hcur, b,
+      k_density<<<cdiv((long long) ((ncur + 63) / 64) * nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
+        t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), sg, ncur, cur, hcur, b,
         P<double>(ctx->drho), P<double>(ctx->dnumngb), P<double>(ctx->ddhsml),
-        P<double>(ctx->ddivv), P<double>(ctx->drot), ng, counter);
+        P<double>(ctx->ddivv), P<double>(ctx->drot), counter);
       k_dens_finalize<<<cdiv(ncur, 256), 256, 0, st>>>(
-        ncur, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
+        ncur, nsub, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
         P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
         P<double>(ctx->dleft), P<double>(ctx->dright), P<double>(ctx->f[GHIP_F_ENTROPY]),
         P<double>(ctx->f[GHIP_F_DTENTROPY]), P<int>(ctx->f[GHIP_F_TIMEBIN]),
@@ -455,7 +511,9 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   TreeDev &t = ctx->st;
   int ng = ctx->ngas;
   GCHK(dens_alloc(ctx));
-  double *hcur = P<double>(ctx->ddhsml) + ng;
+  double *hcur = P<double>(ctx->dhcur);
+  WalkSeg sg;
+  const int nsub = ghip_walk_layout(t, sg);
   int s = 0;
   HIPCHK(hipMemcpyAsync(&s, P<int>(t.iperm) + target, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -464,18 +522,30 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
-  k_density<<<1, GHIP_BLOCK, 0, st>>>(t.nelem, P<double4>(t.cl), P<int4>(t.lk),
-                                      P<double>(ctx->gp), 1, cur, hcur, b, P<double>(ctx->drho),
-                                      P<double>(ctx->dnumngb), P<double>(ctx->ddhsml),
-                                      P<double>(ctx->ddivv), P<double>(ctx->drot), ng, counter);
+  k_density<<<cdiv(nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
+    t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), sg, 1, cur, hcur, b,
+    P<double>(ctx->drho), P<double>(ctx->dnumngb), P<double>(ctx->ddhsml), P<double>(ctx->ddivv),
+    P<double>(ctx->drot), counter);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(&out7[0], P<double>(ctx->drho) + s, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&out7[1], P<double>(ctx->dnumngb) + s, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&out7[2], P<double>(ctx->ddhsml) + s, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&out7[3], P<double>(ctx->ddivv) + s, 8, hipMemcpyDeviceToHost, st));
+  // nt == 1: partial q of component c sits at [q] (rot: [c*nsub + q]); sum in fixed order
+  double part[7][GHIP_MAXSUB * 8];
+  if(nsub > GHIP_MAXSUB * 8)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_density_evaluate: too many sub-walks");
+  HIPCHK(hipMemcpyAsync(part[0], ctx->drho.p, (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(part[1], ctx->dnumngb.p, (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(part[2], ctx->ddhsml.p, (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(part[3], ctx->ddivv.p, (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
   for(int c = 0; c < 3; c++)
-    HIPCHK(hipMemcpyAsync(&out7[4 + c], P<double>(ctx->drot) + (size_t) c * ng + s, 8,
-                          hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(part[4 + c], P<double>(ctx->drot) + (size_t) c * nsub,
+                          (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for(int c = 0; c < 7; c++)
+    {
+      double acc = 0;
+      for(int q = 0; q < nsub; q++)
+        acc += part[c][q];
+      out7[c] = acc;
+    }
   HIPCHK(hipStreamSynchronize(st));
   return GHIP_OK;
 }
@@ -653,19 +723,22 @@ __device__ __forceinline__ void d_hydro_pair(const double *__restrict__ gp,
     }
 }
 
-// hydro_evaluate (hydra.c:822-1995, mode 0) + the entropy-rate conversion of hydro_force
-// (hydra.c:583) for a bucket of 64 targets per wave
+// hydro_evaluate (hydra.c:822-1995, mode 0) for a bucket of 64 targets; `nsub` wavefronts share
+// the bucket (every nsub-th segment of the gas tree's element list each).  Partial sums go to
+// [5][nsub][nt] planes: ax, ay, az, dtentropy, maxsignalvel.
 __global__ void __launch_bounds__(GHIP_BLOCK)
 k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
         const double *__restrict__ aux, const double *__restrict__ gp,
-        const double *__restrict__ gq, int nt, const int *__restrict__ tgt,
-        const int *__restrict__ perm, BoxK b, HydK K, int ngas, double *__restrict__ o_acc,
-        double *__restrict__ o_dtent, double *__restrict__ o_maxsig,
-        unsigned long long *__restrict__ counter)
+        const double *__restrict__ gq, WalkSeg sg, int nt, const int *__restrict__ tgt, BoxK b,
+        HydK K, double *__restrict__ part, unsigned long long *__restrict__ counter)
 {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int ti = wave * 64 + lane;
+  const int bucket = wave / sg.nsub;
+  const int sub = wave - bucket * sg.nsub;
+  if(bucket * 64 >= nt)
+    return;
+  const int ti = bucket * 64 + lane;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
   HydTgt T = {0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 0};
@@ -693,52 +766,91 @@ k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
       T.p_over_rho2_i *= dhf;
     }
   HydAcc A = {0, 0, 0, 0, 0, 0};
+  auto test = [&](int ea, const double4 c) {
+    const double hm = aux[ea];                 // Extnodes[].hmax
+    double dist = (hm > T.h_i) ? hm : T.h_i;   // ngb.c:136
+    return valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
+  };
 
-  int e = 0;
-  while(e < nelem)
+  for(int kseg = sub; kseg < sg.ns; kseg += sg.nsub)
     {
-      e = __builtin_amdgcn_readfirstlane(e);
-      const int4 k = lk[e];
-      if(LK_IS_PARTICLE(k))
+      const int s1 = sg.start[kseg + 1];
+      int e = d_sph_segment_entry(kseg, sg, cl, lk, test);
+      while(e < s1)
         {
-          d_hydro_pair(gp, gq, k.y, valid, T, K, b, A);
-          e = e + 1;
-        }
-      else
-        {
-          const double4 c = cl[e];
-          const double hm = aux[e];  // Extnodes[].hmax
-          double dist = (hm > T.h_i) ? hm : T.h_i;  // ngb.c:136
-          bool open = valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
-          if(__any(open))
+          e = __builtin_amdgcn_readfirstlane(e);
+          const int4 k = lk[e];
+          if(LK_IS_PARTICLE(k))
             {
-              if(k.w <= LEAF_DIRECT)
-                {
-                  for(int j = k.z; j < k.z + k.w; j++)
-                    d_hydro_pair(gp, gq, j, valid, T, K, b, A);
-                  e = k.x;
-                }
-              else
-                e = e + 1;
+              d_hydro_pair(gp, gq, k.y, valid, T, K, b, A);
+              e = e + 1;
             }
           else
-            e = k.x;
+            {
+              const double4 c = cl[e];
+              bool open = test(e, c);
+              if(__any(open))
+                {
+                  if(k.w <= LEAF_DIRECT && k.x <= s1)
+                    {
+                      for(int j = k.z; j < k.z + k.w; j++)
+                        d_hydro_pair(gp, gq, j, valid, T, K, b, A);
+                      e = k.x;
+                    }
+                  else
+                    e = e + 1;
+                }
+              else
+                e = k.x;
+            }
         }
     }
   if(valid)
     {
-      const int i = perm[s];
-      o_acc[i] = A.ax;
-      o_acc[(size_t) ngas + i] = A.ay;
-      o_acc[2 * (size_t) ngas + i] = A.az;
-      // hydra.c:583
-      o_dtent[i] = K.raw ? A.dtent
-                         : A.dtent * (GAMMA_MINUS1 / (K.hubble_a2 * pow(T.rho, GAMMA_MINUS1)));
-      o_maxsig[i] = A.maxsig;
+      const size_t plane = (size_t) sg.nsub * nt;
+      const size_t o = (size_t) sub * nt + ti;
+      part[o] = A.ax;
+      part[plane + o] = A.ay;
+      part[2 * plane + o] = A.az;
+      part[3 * plane + o] = A.dtent;
+      part[4 * plane + o] = A.maxsig;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.np);
   if(lane == 0 && tot)
     atomicAdd(counter, tot);
+}
+
+// fixed-order sum of the partial results + the entropy-rate conversion of hydro_force
+// (hydra.c:583), scattered to host order
+__global__ void k_hydro_combine(int nt, int nsub, const int *__restrict__ tgt,
+                                const int *__restrict__ perm, const double *__restrict__ gq,
+                                const double *__restrict__ part, HydK K, int ngas,
+                                double *__restrict__ o_acc, double *__restrict__ o_dtent,
+                                double *__restrict__ o_maxsig)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  const size_t plane = (size_t) nsub * nt;
+  double ax = 0, ay = 0, az = 0, de = 0, ms = 0;
+  for(int q = 0; q < nsub; q++)
+    {
+      const size_t o = (size_t) q * nt + ti;
+      ax += part[o];
+      ay += part[plane + o];
+      az += part[2 * plane + o];
+      de += part[3 * plane + o];
+      double m = part[4 * plane + o];
+      ms = m > ms ? m : ms;
+    }
+  const int s = tgt[ti];
+  const int i = perm[s];
+  const double rho = gq[(size_t) 8 * s + 1];
+  o_acc[i] = ax;
+  o_acc[(size_t) ngas + i] = ay;
+  o_acc[2 * (size_t) ngas + i] = az;
+  o_dtent[i] = K.raw ? de : de * (GAMMA_MINUS1 / (K.hubble_a2 * pow(rho, GAMMA_MINUS1)));
+  o_maxsig[i] = ms;
 }
 
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
@@ -763,13 +875,19 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
             p->ComovingIntegrationOn, p->raw_dtentropy};
   HIPCHK(hipEventRecord(ctx->ev[10], st));
-  k_hydro<<<cdiv(nt, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
+  WalkSeg sg;
+  const int nsub = ghip_walk_layout(t, sg);
+  GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
+  k_hydro<<<cdiv((long long) ((nt + 63) / 64) * nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
     t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<double>(ctx->gp),
-    P<double>(ctx->gq), nt, P<int>(ctx->tg_gas) + lo, P<int>(t.perm), b, K, ng,
-    P<double>(ctx->f[GHIP_F_HYDROACCEL]), P<double>(ctx->f[GHIP_F_DTENTROPY]),
-    P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]), counter);
+    P<double>(ctx->gq), sg, nt, P<int>(ctx->tg_gas) + lo, b, K, P<double>(ctx->hpart), counter);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[11], st));
+  k_hydro_combine<<<cdiv(nt, 256), 256, 0, st>>>(
+    nt, nsub, P<int>(ctx->tg_gas) + lo, P<int>(t.perm), P<double>(ctx->gq),
+    P<double>(ctx->hpart), K, ng, P<double>(ctx->f[GHIP_F_HYDROACCEL]),
+    P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]));
+  HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
 

@@ -223,7 +223,9 @@ __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ sk
       int o = __shfl_xor(c, off, 64);
       c = o > c ? o : c;
     }
-  if((threadIdx.x & 63) == 0 && c >= 0)
+  // (read first: after the first few wavefronts nobody raises the maximum any more, and 8192
+  // same-address atomics cost 70 us)
+  if((threadIdx.x & 63) == 0 && c > *(volatile int *) maxlevel)
     atomicMax(maxlevel, c);
 }
 
@@ -612,14 +614,22 @@ static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const do
       k_peano_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, sx, sy, sz, ctx->corner[0],
                                                      ctx->corner[1], ctx->corner[2], fac,
                                                      P<unsigned long long>(t.key), P<int>(t.idx));
+      // the order only has to make 64 consecutive targets compact: sort on the leading
+      // ceil(log8 n) + 3 digits of the key (the radix sort's cost is its number of 8-bit passes)
+      int levels = 3;
+      for(long long m = n; m > 1; m >>= 3)
+        levels++;
+      if(levels > GHIP_BITS)
+        levels = GHIP_BITS;
+      int begin_bit = 63 - 3 * levels;
       size_t tb2 = 0;
       HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, P<unsigned long long>(t.key),
                                                 P<unsigned long long>(t.phkey), P<int>(t.idx),
-                                                P<int>(t.phorder), n, 0, 63, st));
+                                                P<int>(t.phorder), n, begin_bit, 63, st));
       GCHK(cub_tmp(ctx, tb2));
       HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb2, P<unsigned long long>(t.key),
                                                 P<unsigned long long>(t.phkey), P<int>(t.idx),
-                                                P<int>(t.phorder), n, 0, 63, st));
+                                                P<int>(t.phorder), n, begin_bit, 63, st));
     }
   HIPCHK(hipGetLastError());
   t.built = true;
@@ -658,7 +668,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
     {
       GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
       k_inverse_perm<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->gt.perm), P<int>(ctx->gt.iperm));
-      GCHK(ghip_build_segments(ctx, ctx->gt));
+      GCHK(ghip_build_segments(ctx, ctx->gt, true));
       GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
       GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
       GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
@@ -680,6 +690,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
       k_inverse_perm<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(ctx->st.perm),
                                                     P<int>(ctx->st.iperm));
+      GCHK(ghip_build_segments(ctx, ctx->st, false));
       GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
       GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
       const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);

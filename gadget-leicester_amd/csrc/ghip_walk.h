@@ -24,17 +24,18 @@
 // interaction happen exactly once; the S partial sums per target are added in fixed order
 // afterwards (k_combine_grav), so results are deterministic.
 //
-// Latency.  The walk is a pointer chase: the next element is known only after the vote.  Two
-// things keep the SIMDs fed: (i) the record a step needs is ONE 64-byte scalar load (the "hot"
-// half: monopole, opening-criterion operands, links); the "cold" half (cell centre, len) is
-// fetched only when a lane may sit inside the cell or a special walk needs it; (ii) each wavefront
-// advances TWO of its segments at once -- both loads are in flight together, then both elements
-// are processed -- so a step costs half a memory latency.  No MFMA: irregular fp64 work.
+// Latency.  The walk is a pointer chase: the next element is known only after the vote.  The
+// record a step needs is ONE 64-byte scalar load (the "hot" half: monopole, opening-criterion
+// operands, links); the "cold" half (cell centre, len) is fetched only when a lane may sit
+// inside the cell or a special walk needs it.  Occupancy (registers) hides the rest.
+// No MFMA: irregular fp64 work.
 #pragma once
 #include "ghip_internal.h"
 
-#define GHIP_MAXANC 24
-#define GHIP_MAXSUB 8
+#ifndef GHIP_WALK_WAVES
+#define GHIP_WALK_WAVES 8   // wavefronts per SIMD the register allocator must leave room for
+#endif
+
 
 struct GravK
 {
@@ -46,15 +47,6 @@ struct GravK
   int xcd_remap;       // GHIP_WALK_XCD=0 disables the XCD-contiguous block order
   double rcut, rcut2, asmthfac;  // shortrange
   double fac_intp;     // ewald: 2*EN/BoxSize
-};
-
-struct WalkSeg
-{
-  int ns;                          // number of segments
-  int nsub;                        // wavefronts per bucket
-  const int *__restrict__ start;   // [ns+1] first element of each segment
-  const int *__restrict__ nanc;    // [ns]
-  const int *__restrict__ anc;     // [ns][GHIP_MAXANC] ancestors of start[k], root first
 };
 
 // hot half of an element (64 B):  x, y, z, mass | (mass*len)*len, len*len | skip, pidx | aux
@@ -390,15 +382,15 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   return next;
 }
 
-__device__ __forceinline__ int d_wave_min_i32(int v)
+// which wavefront works for which bucket (see "adaptive split" below)
+struct WalkPlan
 {
-  for(int off = 32; off > 0; off >>= 1)
-    {
-      int o = __shfl_xor(v, off, 64);
-      v = o < v ? o : v;
-    }
-  return v;
-}
+  int nwaves;                            // wavefronts launched
+  const int *__restrict__ wave_bucket;   // [nwaves] bucket of each wavefront, -1: idle
+  const int *__restrict__ woff;          // [nbuckets] first wavefront of the bucket
+  const int *__restrict__ nsub;          // [nbuckets] wavefronts sharing the bucket
+  unsigned int *__restrict__ steps_out;  // [nbuckets] elements visited (summed over wavefronts)
+};
 
 // cursor over the segments one wavefront owns through one of its two slots
 struct SegCursor
@@ -446,23 +438,26 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
 // round-robin over the 8 XCDs) works through ONE contiguous eighth of the buckets: neighbouring
 // buckets read the same deep tree nodes, which then stay in that XCD's 4 MB L2.
 template <int MODE, bool PERIODIC>
-__global__ void __launch_bounds__(GHIP_BLOCK)
+__global__ void __launch_bounds__(GHIP_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == GHIP_WALK_EWALD ? 4 : GHIP_WALK_WAVES, 8)))
 k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restrict__ cold,
             WalkSeg sg, int nt, const int *__restrict__ tgt, const double *__restrict__ tx,
             const double *__restrict__ ty, const double *__restrict__ tz,
             const double *__restrict__ tsoft, const double *__restrict__ toldacc, GravK p,
             const float *__restrict__ srtab, const EwEntry *__restrict__ ewtab,
             double *__restrict__ pax, double *__restrict__ pay, double *__restrict__ paz,
-            int *__restrict__ pcost, unsigned long long *__restrict__ counter)
+            int *__restrict__ pcost, unsigned long long *__restrict__ counter, WalkPlan plan)
 {
   const int lane = threadIdx.x & 63;
   const int per_xcd = gridDim.x >> 3;
   const int lblock = p.xcd_remap ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const int wave = (lblock * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int bucket = wave / sg.nsub;
-  const int sub = wave - bucket * sg.nsub;
-  if(bucket * 64 >= nt)
+  const int wave = __builtin_amdgcn_readfirstlane((lblock * (int) blockDim.x + threadIdx.x) >> 6);
+  if(wave >= plan.nwaves)
     return;
+  const int bucket = __builtin_amdgcn_readfirstlane(plan.wave_bucket[wave]);
+  if(bucket < 0 || bucket * 64 >= nt)
+    return;
+  const int sub = wave - __builtin_amdgcn_readfirstlane(plan.woff[bucket]);
+  sg.nsub = __builtin_amdgcn_readfirstlane(plan.nsub[bucket]);   // wavefronts sharing THIS bucket
   const int ti = bucket * 64 + lane;
   const bool valid = ti < nt;
   const int s = valid ? (tgt ? tgt[ti] : ti) : 0;
@@ -485,47 +480,14 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   W.nint = 0;
   unsigned int steps = 0;
 
-  // two slots: A owns segments sub, sub+2S, ...; B owns sub+S, sub+3S, ...
-  SegCursor A, B;
-  int skipA = 0, skipB = 0;
+  // this wavefront owns segments sub, sub+S, sub+2S, ...  (advancing two segments at once, both
+  // loads in flight together, was measured: no gain, +9 VGPRs -- the walk is issue-bound)
+  SegCursor A;
+  int skipA = 0;
   A.kseg = sub;
-  B.kseg = sub + sg.nsub;
-  const int stride = 2 * sg.nsub;
+  const int stride = sg.nsub;
   bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid, W,
                                                skipA, steps);
-  bool liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid, W,
-                                               skipB, steps);
-  while(liveA && liveB)
-    {
-      v16i HA, HB;
-      d_issue_load(hot, A.e, HA);
-      d_issue_load(hot, B.e, HB);
-      d_wait2(HA, HB);
-      steps += 2;
-      A.e = __builtin_amdgcn_readfirstlane(
-        d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
-      B.e = __builtin_amdgcn_readfirstlane(
-        d_walk_element<MODE, PERIODIC, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
-      if(A.e >= A.s1)
-        {
-          A.kseg += stride;
-          liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                  W, skipA, steps);
-        }
-      if(B.e >= B.s1)
-        {
-          B.kseg += stride;
-          liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                  W, skipB, steps);
-        }
-    }
-  // drain whichever slot is still live, one element at a time
-  if(liveB)
-    {
-      A = B;
-      skipA = skipB;
-      liveA = true;
-    }
   while(liveA)
     {
       v16i HA;
@@ -544,7 +506,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
 
   if(valid)
     {
-      const size_t o = (size_t) sub * nt + ti;
+      const size_t o = (size_t) wave * 64 + lane;   // wave-major partials
       pax[o] = W.acc_x;
       pay[o] = W.acc_y;
       paz[o] = W.acc_z;
@@ -554,7 +516,55 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   if(lane == 0 && tot)
     atomicAdd(counter, tot);
   if(lane == 0)
-    atomicAdd(counter + 8, (unsigned long long) steps);
+    {
+      atomicAdd(counter + 8, (unsigned long long) steps);
+      atomicAdd(plan.steps_out + bucket, steps);   // cost model of the next call's plan
+    }
+}
+
+// ---- adaptive split: how many wavefronts share each bucket ----------------------------------
+// The previous call of the same walk recorded the elements visited per bucket.  A bucket gets
+// floor(S*steps/mean)+1 wavefronts (2..64, never more than there are segments), so every
+// wavefront walks about the same number of elements and the kernel has no long tail.  S is 8
+// for a full-size launch and grows (up to one wavefront per segment) when there are few buckets
+// -- one rank's share of a multi-GPU run -- so that the chip still sees ~50 000 wavefronts: a
+// wavefront is a serial chain of dependent loads, only their number hides the latency.  The sum
+// is bounded by S+2 per bucket on average, which is what the grid is sized for.
+__global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__restrict__ steps_prev,
+                            const unsigned long long *__restrict__ total_prev, int have_prev,
+                            int *__restrict__ nsub)
+{
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= nb)
+    return;
+  int s = ns < sbase ? ns : sbase;
+  if(have_prev)
+    {
+      double mean = (double) (*total_prev) / (double) nb;
+      if(mean > 0)
+        {
+          s = (int) ((double) sbase * (double) steps_prev[b] / mean) + 1;
+          s = s < 2 ? 2 : s;
+          s = s > 64 ? 64 : s;
+        }
+      if(s > ns)
+        s = ns;
+    }
+  nsub[b] = s < 1 ? 1 : s;
+}
+
+__global__ void k_plan_fill(int nb, const int *__restrict__ nsub, const int *__restrict__ woff,
+                            int maxwaves, int *__restrict__ wave_bucket,
+                            unsigned int *__restrict__ steps_out)
+{
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= nb)
+    return;
+  int o = woff[b], s = nsub[b];
+  for(int q = 0; q < s; q++)
+    if(o + q < maxwaves)
+      wave_bucket[o + q] = b;
+  steps_out[b] = 0;
 }
 
 // segment table of a tree: equal-length slices of the element list + the ancestor chain of each
@@ -593,7 +603,7 @@ __global__ void k_build_segments(int nelem, const int4 *__restrict__ lk, int ns,
 
 // sum the per-wavefront partial results of each target in fixed order and scatter to host order;
 // EWALD adds to the stored values (forcetree.c:3190-3193)
-__global__ void k_combine_grav(int nt, int nsub, const int *__restrict__ tgt,
+__global__ void k_combine_grav(int nt, WalkPlan plan, const int *__restrict__ tgt,
                                const int *__restrict__ perm, const double *__restrict__ pax,
                                const double *__restrict__ pay, const double *__restrict__ paz,
                                const int *__restrict__ pcost, int n, double *__restrict__ oacc,
@@ -602,11 +612,13 @@ __global__ void k_combine_grav(int nt, int nsub, const int *__restrict__ tgt,
   int ti = blockIdx.x * blockDim.x + threadIdx.x;
   if(ti >= nt)
     return;
+  const int bucket = ti >> 6, lane = ti & 63;
+  const int w0 = plan.woff[bucket], nsub = plan.nsub[bucket];
   double a0 = 0, a1 = 0, a2 = 0;
   int c = 0;
   for(int s = 0; s < nsub; s++)
     {
-      size_t o = (size_t) s * nt + ti;
+      size_t o = (size_t) (w0 + s) * 64 + lane;
       a0 += pax[o];
       a1 += pay[o];
       a2 += paz[o];
