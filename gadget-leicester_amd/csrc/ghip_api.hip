@@ -81,6 +81,13 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         return GHIP_EHIP;
       }
   ctx->ev_ready = true;
+  // device counters start at zero (hipMalloc does not clear)
+  if(ghip_ensure(ctx, ctx->counters, 64 * 8) != GHIP_OK ||
+     hipMemset(ctx->counters.p, 0, ctx->counters.cap) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_ENOMEM;
+    }
   // make every event "recorded" so that elapsed-time queries never fault
   for(int i = 0; i < 12; i++)
     (void) hipEventRecord(ctx->ev[i], ctx->stream);

@@ -206,7 +206,10 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
   k.fac_intp = (p->BoxSize > 0) ? 2 * GHIP_EN / p->BoxSize : 0;
   k.debug_steps = getenv("GHIP_DEBUG_STEPS") ? 1 : 0;
-  k.xcd_remap = (getenv("GHIP_WALK_XCD") && atoi(getenv("GHIP_WALK_XCD")) == 0) ? 0 : 1;
+  // XCD-contiguous block order: off by default -- with the adaptive plan the grid is sized for
+  // the worst case and its idle tail would all land on the last XCD (measured: Ewald walk 8.4 vs
+  // 7.7 ms); the L2 locality it buys was within noise (12.9 vs 13.1 ms)
+  k.xcd_remap = (getenv("GHIP_WALK_XCD") && atoi(getenv("GHIP_WALK_XCD")) == 1) ? 1 : 0;
   if(walk == GHIP_WALK_SHORTRANGE)
     {
       if(!(p->Asmth > 0) || !(p->Rcut > 0))
@@ -240,7 +243,6 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
 // segment table of the gravity tree; called at the end of every tree build
 int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
 {
-  const bool gas_tree = !walk_records;
   t.ns = 1;
   if(t.n == 0)
     return GHIP_OK;
@@ -258,24 +260,21 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
       if(v >= 1 && v <= 4096)
         ns = v;
     }
-  if(gas_tree)
-    {
-      // the SPH walks touch 1-2 of 64 segments per bucket, so splitting them only adds ancestor
-      // replays (measured: density +50 %, hydro +60 % at c2); kept switchable for experiments
-      ns = 1;
-      if(getenv("GHIP_SPH_SEGMENTS"))
-        {
-          int v = atoi(getenv("GHIP_SPH_SEGMENTS"));
-          if(v >= 1 && v <= 4096)
-            ns = v;
-        }
-    }
+  // a second, 4x coarser table for the Ewald walk: it visits ~6x fewer elements per bucket, so
+  // the ancestor replays of a fine table would be a third of its work
+  int ns2 = ns / 4;
+  if(ns2 < 1)
+    ns2 = 1;
   t.ns = ns;
-  GCHK(ghip_ensure(ctx, t.seg_start, (size_t) (ns + 1) * 4));
-  GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) ns * 4));
-  GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) ns * GHIP_MAXANC * 4));
+  t.ns2 = ns2;
+  GCHK(ghip_ensure(ctx, t.seg_start, (size_t) (ns + 1 + ns2 + 1) * 4));
+  GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) (ns + ns2) * 4));
+  GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) (ns + ns2) * GHIP_MAXANC * 4));
   k_build_segments<<<cdiv(ns + 1, 64), 64, 0, ctx->stream>>>(
     t.nelem, P<int4>(t.lk), ns, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
+  k_build_segments<<<cdiv(ns2 + 1, 64), 64, 0, ctx->stream>>>(
+    t.nelem, P<int4>(t.lk), ns2, P<int>(t.seg_start) + ns + 1, P<int>(t.seg_nanc) + ns,
+    P<int>(t.seg_anc) + (size_t) ns * GHIP_MAXANC);
   HIPCHK(hipGetLastError());
   if(!walk_records)
     return GHIP_OK;
@@ -289,28 +288,28 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   return GHIP_OK;
 }
 
-int ghip_walk_layout(const TreeDev &t, WalkSeg &sg)
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, bool coarse)
 {
-  sg.ns = t.ns;
-  sg.nsub = t.ns < GHIP_MAXSUB ? t.ns : GHIP_MAXSUB;
+  sg.ns = coarse ? t.ns2 : t.ns;
+  sg.nsub = sg.ns < GHIP_MAXSUB ? sg.ns : GHIP_MAXSUB;
   if(getenv("GHIP_WALK_SUBS"))
     {
       int v = atoi(getenv("GHIP_WALK_SUBS"));
-      if(v >= 1 && v <= t.ns)
+      if(v >= 1 && v <= sg.ns)
         sg.nsub = v;
     }
   if(sg.nsub < 1)
     sg.nsub = 1;
-  sg.start = P<int>(t.seg_start);
-  sg.nanc = P<int>(t.seg_nanc);
-  sg.anc = P<int>(t.seg_anc);
+  sg.start = P<int>(t.seg_start) + (coarse ? t.ns + 1 : 0);
+  sg.nanc = P<int>(t.seg_nanc) + (coarse ? t.ns : 0);
+  sg.anc = P<int>(t.seg_anc) + (coarse ? (size_t) t.ns * GHIP_MAXANC : 0);
   return sg.nsub;
 }
 
-static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets)
+static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, bool coarse)
 {
   *nbuckets = (nt + 63) / 64;
-  return ghip_walk_layout(t, sg);
+  return ghip_walk_layout(t, sg, coarse);
 }
 
 static int ensure_partials(ghip_ctx *ctx, int nwaves)
@@ -462,7 +461,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   const int *tgt = P<int>(ctx->tg_grav) + lo;
   WalkSeg sg;
   int nbuckets;
-  walk_layout(ctx->gt, nt, sg, &nbuckets);
+  walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
   WalkPlan plan;
   GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, nbuckets, sg.ns, plan));
   GCHK(ensure_partials(ctx, plan.nwaves));
@@ -545,7 +544,7 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
                                                   p->ForceSoftening[5], dsoft);
   WalkSeg sg;
   int nbuckets;
-  walk_layout(ctx->gt, nt, sg, &nbuckets);
+  walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
   WalkPlan plan;
   GCHK(build_plan(ctx, 2, nbuckets, sg.ns, plan));
   GCHK(ensure_partials(ctx, plan.nwaves));

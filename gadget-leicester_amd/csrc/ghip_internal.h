@@ -40,7 +40,7 @@ struct TreeDev
   DevBuf xm, cl, lk, aux;              // double4[nelem], double4[nelem], int4[nelem], f64[nelem]
   // walk segments (ghip_walk.h): start[ns+1], nanc[ns], anc[ns][GHIP_MAXANC]
   DevBuf seg_start, seg_nanc, seg_anc;
-  int ns = 1;
+  int ns = 1, ns2 = 1;   // fine table (Newton / short-range walk), coarse table (Ewald walk)
   DevBuf mq, mq2;                      // WalkHot[nelem], WalkCold[nelem]: walk records (gravity tree)
   bool built = false;
 };
@@ -170,6 +170,7 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records);
 // sph.hip
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p);
+int ghip_sph_fill_nodes(ghip_ctx *ctx, bool hmax_only);
 
 // ---------------------------------------------------------------------------------------------
 // walk segments: the element list of a tree is cut into `ns` contiguous segments and `nsub`
@@ -187,7 +188,7 @@ struct WalkSeg
   const int *__restrict__ anc;     // [ns][GHIP_MAXANC] ancestors of start[k], root first
 };
 
-int ghip_walk_layout(const TreeDev &t, WalkSeg &sg);   // returns nsub
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, bool coarse);   // returns nsub
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

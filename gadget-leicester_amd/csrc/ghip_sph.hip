@@ -77,12 +77,13 @@ struct DensAcc
   int nn;
 };
 
-__device__ __forceinline__ void d_density_pair(const double *__restrict__ gp, int j, bool valid,
+// r8: the candidate's record (x,y,z,m,vx,vy,vz,h) -- a wave-uniform global address (scalar
+// loads) or a slot of the LDS staging area (broadcast ds_read)
+__device__ __forceinline__ void d_density_pair(const double *r8, bool valid,
                                                double px, double py, double pz, double vx,
                                                double vy, double vz, double h2, double hinv,
                                                double hinv3, double hinv4, const BoxK b, DensAcc &A)
 {
-  const double *r8 = gp + (size_t) 8 * j;  // wave-uniform address: scalar loads
   const double jx = r8[0], jy = r8[1], jz = r8[2], mass_j = r8[3];
   const double jvx = r8[4], jvy = r8[5], jvz = r8[6];
   double dx = d_wrap(px - jx, b), dy = d_wrap(py - jy, b), dz = d_wrap(pz - jz, b);
@@ -117,44 +118,51 @@ __device__ __forceinline__ void d_density_pair(const double *__restrict__ gp, in
     }
 }
 
-// first element of segment kseg that the wave still has to look at: replays the node test at the
-// segment's ancestors (outermost first); the first ancestor NO lane overlaps prunes everything up
-// to its skip index
-template <class LaneTest>
-__device__ __forceinline__ int d_sph_segment_entry(int kseg, const WalkSeg &sg,
-                                                  const double4 *__restrict__ cl,
-                                                  const int4 *__restrict__ lk, LaneTest test)
+// One element of the gas tree as the SPH walks read it (64 B, one s_load_dwordx16):
+//   cx, cy, cz, len | hmax | skip, pidx, pstart, pcount | pad
+struct __attribute__((aligned(64))) SphNode
 {
-  int e = sg.start[kseg];
-  const int na = sg.nanc[kseg];
-  for(int a = 0; a < na; a++)
-    {
-      int ea = __builtin_amdgcn_readfirstlane(sg.anc[kseg * GHIP_MAXANC + a]);
-      if(!__any(test(ea, cl[ea])))
-        {
-          int sk = lk[ea].x;
-          return sk > e ? sk : e;
-        }
-    }
-  return e;
+  double cx, cy, cz, len;
+  double hmax;
+  int skip, pidx, pstart, pcount;
+  int pad[2];
+};
+typedef int v16i_s __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ double d_f64s(const v16i_s &v, int i)
+{
+  return __hiloint2double(v[2 * i + 1], v[2 * i]);
 }
 
-// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 targets; `nsub` wavefronts
-// share the bucket, each walking every nsub-th segment of the gas tree's element list.  Partial
-// sums go to [sub][nt] planes (summed in fixed order by k_dens_finalize).
-__global__ void __launch_bounds__(GHIP_BLOCK)
-k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-          const double *__restrict__ gp, WalkSeg sg, int nt, const int *__restrict__ tgt,
-          const double *__restrict__ hcur, BoxK b, double *__restrict__ prho,
-          double *__restrict__ pnum, double *__restrict__ pdh, double *__restrict__ pdiv,
-          double *__restrict__ prot, unsigned long long *__restrict__ counter)
+__device__ __forceinline__ void d_load_sphnode(const SphNode *__restrict__ base, int e, v16i_s &R)
 {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int bucket = wave / sg.nsub;
-  const int sub = wave - bucket * sg.nsub;
-  if(bucket * 64 >= nt)
-    return;
+  unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
+  unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
+  const SphNode *p = reinterpret_cast<const SphNode *>(((unsigned long long) hi << 32) | lo);
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(R) : "s"(p) : "memory");
+}
+
+#define SPH_STAGE 64   // candidates staged through LDS per node (= lanes of the staging load)
+
+// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 curve-consecutive targets.
+// One wavefront per workgroup.  Node records come through the scalar path; when a node with
+// <= 64 gas particles overlaps any lane's search sphere its particle records (contiguous in
+// gas-tree order) are fetched with ONE coalesced vector load -- lane l loads candidate l --
+// into LDS, and every lane then reads candidate j as a broadcast ds_read: one memory latency per
+// 64 candidates instead of one per candidate.  Each lane applies the exact test r2 < h_i^2.
+__global__ void __launch_bounds__(64)
+k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp, int nt,
+          int nsub, const int *__restrict__ tgt, const double *__restrict__ hcur, BoxK b,
+          double *__restrict__ prho, double *__restrict__ pnum, double *__restrict__ pdh,
+          double *__restrict__ pdiv, double *__restrict__ prot,
+          unsigned long long *__restrict__ counter)
+{
+  __shared__ double4 sh[SPH_STAGE][2];
+  const int lane = threadIdx.x;
+  const int bucket = blockIdx.x / nsub;
+  const int sub = blockIdx.x - bucket * nsub;   // this wavefront takes every nsub-th batch
+  int batch = 0;
   const int ti = bucket * 64 + lane;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
@@ -173,48 +181,57 @@ k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk
   const double h2 = h * h, hinv = 1.0 / h;
   const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv;
   DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto test = [&](int, const double4 c) { return valid && d_node_overlaps(c, h, px, py, pz, b); };
 
-  for(int kseg = sub; kseg < sg.ns; kseg += sg.nsub)
+  int e = 0;
+  while(e < nelem)
     {
-      const int s1 = sg.start[kseg + 1];
-      int e = d_sph_segment_entry(kseg, sg, cl, lk, test);
-      while(e < s1)
+      e = __builtin_amdgcn_readfirstlane(e);
+      v16i_s N;
+      d_load_sphnode(nodes, e, N);
+      const int skip = N[10], pidx = N[11], pstart = N[12], pcount = N[13];
+      if(pidx >= 0)
         {
-          e = __builtin_amdgcn_readfirstlane(e);
-          const int4 k = lk[e];
-          if(LK_IS_PARTICLE(k))
+          if((batch++ % nsub) == sub)
+            d_density_pair(gp + (size_t) 8 * pidx, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3,
+                           hinv4, b, A);
+          e = e + 1;
+        }
+      else
+        {
+          const double4 c = make_double4(d_f64s(N, 0), d_f64s(N, 1), d_f64s(N, 2), d_f64s(N, 3));
+          bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
+          if(__any(open))
             {
-              d_density_pair(gp, k.y, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
-              e = e + 1;
-            }
-          else
-            {
-              const double4 c = cl[e];
-              bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
-              if(__any(open))
+              if(pcount <= SPH_STAGE)
                 {
-                  // flat sweep only if the whole subtree lies inside this segment (its
-                  // particles are owned by the segments their elements fall in)
-                  if(k.w <= LEAF_DIRECT && k.x <= s1)
+                  if((batch++ % nsub) == sub)
                     {
-                      for(int j = k.z; j < k.z + k.w; j++)
-                        d_density_pair(gp, j, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4,
-                                       b, A);
-                      e = k.x;
+                      __syncthreads();   // previous batch fully consumed
+                      if(lane < pcount)
+                        {
+                          const double4 *src =
+                            reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
+                          sh[lane][0] = src[0];
+                          sh[lane][1] = src[1];
+                        }
+                      __syncthreads();
+                      for(int j = 0; j < pcount; j++)
+                        d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px, py,
+                                       pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
                     }
-                  else
-                    e = e + 1;
+                  e = skip;
                 }
               else
-                e = k.x;
+                e = e + 1;
             }
+          else
+            e = skip;
         }
     }
   if(valid)
     {
       const size_t o = (size_t) sub * nt + ti;
-      const size_t plane = (size_t) sg.nsub * nt;
+      const size_t plane = (size_t) nsub * nt;
       prho[o] = A.rho;
       pnum[o] = A.wnum;
       pdh[o] = A.dhsml;
@@ -226,6 +243,54 @@ k_density(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.nn);
   if(lane == 0 && tot)
     atomicAdd(counter, tot);
+}
+
+// SphNode records from the gas tree's arrays; k_sph_nodes_hmax refreshes only hmax
+__global__ void k_fill_sph_nodes(int nelem, const double4 *__restrict__ cl,
+                                 const int4 *__restrict__ lk, const double *__restrict__ aux,
+                                 SphNode *__restrict__ out)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  double4 c = cl[e];
+  int4 k = lk[e];
+  SphNode r;
+  r.cx = c.x;
+  r.cy = c.y;
+  r.cz = c.z;
+  r.len = c.w;
+  r.hmax = aux[e];
+  r.skip = k.x;
+  r.pidx = k.y;
+  r.pstart = k.z;
+  r.pcount = k.w;
+  r.pad[0] = r.pad[1] = 0;
+  out[e] = r;
+}
+
+__global__ void k_sph_nodes_hmax(int nelem, const double *__restrict__ aux,
+                                 SphNode *__restrict__ nodes)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e < nelem)
+    nodes[e].hmax = aux[e];
+}
+
+int ghip_sph_fill_nodes(ghip_ctx *ctx, bool hmax_only)
+{
+  TreeDev &t = ctx->st;
+  if(t.n == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(SphNode)));
+  if(hmax_only)
+    k_sph_nodes_hmax<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double>(t.aux),
+                                                                  P<SphNode>(t.mq));
+  else
+    k_fill_sph_nodes<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(
+      t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<SphNode>(t.mq));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
 }
 
 __global__ void k_dens_init(int nt, const int *__restrict__ tgt, const double *__restrict__ gp,
@@ -418,8 +483,6 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   TreeDev &t = ctx->st;
   GCHK(dens_alloc(ctx));
   double *hcur = P<double>(ctx->dhcur);
-  WalkSeg sg;
-  const int nsub = ghip_walk_layout(t, sg);
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 4;
   int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
@@ -441,10 +504,15 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 
   while(ncur > 0)
     {
-      k_density<<<cdiv((long long) ((ncur + 63) / 64) * nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
-        t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), sg, ncur, cur, hcur, b,
-        P<double>(ctx->drho), P<double>(ctx->dnumngb), P<double>(ctx->ddhsml),
-        P<double>(ctx->ddivv), P<double>(ctx->drot), counter);
+      // wavefronts per bucket: enough of them to occupy the chip when the target list is short
+      // (late h-iterations, one rank's share of a multi-GPU run); each takes every nsub-th batch
+      const int nbk = (ncur + 63) / 64;
+      int nsub = (8192 + nbk - 1) / nbk;
+      nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
+      k_density<<<nbk * nsub, 64, 0, st>>>(
+        t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur, nsub, cur, hcur, b, P<double>(ctx->drho),
+        P<double>(ctx->dnumngb), P<double>(ctx->ddhsml), P<double>(ctx->ddivv),
+        P<double>(ctx->drot), counter);
       k_dens_finalize<<<cdiv(ncur, 256), 256, 0, st>>>(
         ncur, nsub, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
         P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
@@ -512,8 +580,7 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   int ng = ctx->ngas;
   GCHK(dens_alloc(ctx));
   double *hcur = P<double>(ctx->dhcur);
-  WalkSeg sg;
-  const int nsub = ghip_walk_layout(t, sg);
+  const int nsub = 1;
   int s = 0;
   HIPCHK(hipMemcpyAsync(&s, P<int>(t.iperm) + target, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -522,10 +589,10 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
-  k_density<<<cdiv(nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
-    t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(ctx->gp), sg, 1, cur, hcur, b,
-    P<double>(ctx->drho), P<double>(ctx->dnumngb), P<double>(ctx->ddhsml), P<double>(ctx->ddivv),
-    P<double>(ctx->drot), counter);
+  k_density<<<nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
+                              P<double>(ctx->drho), P<double>(ctx->dnumngb),
+                              P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot),
+                              counter);
   HIPCHK(hipGetLastError());
   // nt == 1: partial q of component c sits at [q] (rot: [c*nsub + q]); sum in fixed order
   double part[7][GHIP_MAXSUB * 8];
@@ -649,13 +716,10 @@ struct HydTgt
   double px, py, pz, vx, vy, vz, h_i, h_i2, mass, rho, f1, p_over_rho2_i, soundspeed_i, timestep;
 };
 
-__device__ __forceinline__ void d_hydro_pair(const double *__restrict__ gp,
-                                             const double *__restrict__ gq, int j, bool valid,
+__device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8, bool valid,
                                              const HydTgt &T, const HydK &K, const BoxK b,
                                              HydAcc &A)
 {
-  const double *r8 = gp + (size_t) 8 * j;  // wave-uniform: scalar loads
-  const double *q8 = gq + (size_t) 8 * j;
   const double jx = r8[0], jy = r8[1], jz = r8[2], mass_j = r8[3];
   const double jvx = r8[4], jvy = r8[5], jvz = r8[6], h_j = r8[7];
   double dx = d_wrap(T.px - jx, b), dy = d_wrap(T.py - jy, b), dz = d_wrap(T.pz - jz, b);
@@ -723,21 +787,20 @@ __device__ __forceinline__ void d_hydro_pair(const double *__restrict__ gp,
     }
 }
 
-// hydro_evaluate (hydra.c:822-1995, mode 0) for a bucket of 64 targets; `nsub` wavefronts share
-// the bucket (every nsub-th segment of the gas tree's element list each).  Partial sums go to
-// [5][nsub][nt] planes: ax, ay, az, dtentropy, maxsignalvel.
-__global__ void __launch_bounds__(GHIP_BLOCK)
-k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-        const double *__restrict__ aux, const double *__restrict__ gp,
-        const double *__restrict__ gq, WalkSeg sg, int nt, const int *__restrict__ tgt, BoxK b,
-        HydK K, double *__restrict__ part, unsigned long long *__restrict__ counter)
+// hydro_evaluate (hydra.c:822-1995, mode 0) for a bucket of 64 curve-consecutive targets, same
+// structure as k_density: scalar node records, candidate records (gp + gq, 128 B) staged through
+// LDS 64 at a time, exact per-lane acceptance r2 < h_i^2 || r2 < h_j^2.  Node pruning uses
+// max(hmax_node, h_i) like ngb_treefind_pairs (ngb.c:136).  Outputs: [5][nt] planes.
+__global__ void __launch_bounds__(64)
+k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp,
+        const double *__restrict__ gq, int nt, int nsub, const int *__restrict__ tgt, BoxK b, HydK K,
+        double *__restrict__ part, unsigned long long *__restrict__ counter)
 {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * GHIP_BLOCK + threadIdx.x) >> 6;
-  const int bucket = wave / sg.nsub;
-  const int sub = wave - bucket * sg.nsub;
-  if(bucket * 64 >= nt)
-    return;
+  __shared__ double4 sh[SPH_STAGE][4];
+  const int lane = threadIdx.x;
+  const int bucket = blockIdx.x / nsub;
+  const int sub = blockIdx.x - bucket * nsub;
+  int batch = 0;
   const int ti = bucket * 64 + lane;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
@@ -766,48 +829,61 @@ k_hydro(int nelem, const double4 *__restrict__ cl, const int4 *__restrict__ lk,
       T.p_over_rho2_i *= dhf;
     }
   HydAcc A = {0, 0, 0, 0, 0, 0};
-  auto test = [&](int ea, const double4 c) {
-    const double hm = aux[ea];                 // Extnodes[].hmax
-    double dist = (hm > T.h_i) ? hm : T.h_i;   // ngb.c:136
-    return valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
-  };
 
-  for(int kseg = sub; kseg < sg.ns; kseg += sg.nsub)
+  int e = 0;
+  while(e < nelem)
     {
-      const int s1 = sg.start[kseg + 1];
-      int e = d_sph_segment_entry(kseg, sg, cl, lk, test);
-      while(e < s1)
+      e = __builtin_amdgcn_readfirstlane(e);
+      v16i_s N;
+      d_load_sphnode(nodes, e, N);
+      const int skip = N[10], pidx = N[11], pstart = N[12], pcount = N[13];
+      if(pidx >= 0)
         {
-          e = __builtin_amdgcn_readfirstlane(e);
-          const int4 k = lk[e];
-          if(LK_IS_PARTICLE(k))
+          if((batch++ % nsub) == sub)
+            d_hydro_pair(gp + (size_t) 8 * pidx, gq + (size_t) 8 * pidx, valid, T, K, b, A);
+          e = e + 1;
+        }
+      else
+        {
+          const double4 c = make_double4(d_f64s(N, 0), d_f64s(N, 1), d_f64s(N, 2), d_f64s(N, 3));
+          const double hm = d_f64s(N, 4);            // Extnodes[].hmax
+          double dist = (hm > T.h_i) ? hm : T.h_i;   // ngb.c:136
+          bool open = valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
+          if(__any(open))
             {
-              d_hydro_pair(gp, gq, k.y, valid, T, K, b, A);
-              e = e + 1;
-            }
-          else
-            {
-              const double4 c = cl[e];
-              bool open = test(e, c);
-              if(__any(open))
+              if(pcount <= SPH_STAGE)
                 {
-                  if(k.w <= LEAF_DIRECT && k.x <= s1)
+                  if((batch++ % nsub) == sub)
                     {
-                      for(int j = k.z; j < k.z + k.w; j++)
-                        d_hydro_pair(gp, gq, j, valid, T, K, b, A);
-                      e = k.x;
+                  __syncthreads();
+                  if(lane < pcount)
+                    {
+                      const double4 *s0 =
+                        reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
+                      const double4 *s1 =
+                        reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + lane));
+                      sh[lane][0] = s0[0];
+                      sh[lane][1] = s0[1];
+                      sh[lane][2] = s1[0];
+                      sh[lane][3] = s1[1];
                     }
-                  else
-                    e = e + 1;
+                  __syncthreads();
+                  for(int j = 0; j < pcount; j++)
+                    d_hydro_pair(reinterpret_cast<const double *>(&sh[j][0]),
+                                 reinterpret_cast<const double *>(&sh[j][2]), valid, T, K, b, A);
+                    }
+                  e = skip;
                 }
               else
-                e = k.x;
+                e = e + 1;
             }
+          else
+            e = skip;
         }
     }
   if(valid)
     {
-      const size_t plane = (size_t) sg.nsub * nt;
+      const size_t plane = (size_t) nsub * nt;
       const size_t o = (size_t) sub * nt + ti;
       part[o] = A.ax;
       part[plane + o] = A.ay;
@@ -875,12 +951,13 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
             p->ComovingIntegrationOn, p->raw_dtentropy};
   HIPCHK(hipEventRecord(ctx->ev[10], st));
-  WalkSeg sg;
-  const int nsub = ghip_walk_layout(t, sg);
+  const int nbk = (nt + 63) / 64;
+  int nsub = (8192 + nbk - 1) / nbk;
+  nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
   GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
-  k_hydro<<<cdiv((long long) ((nt + 63) / 64) * nsub * 64, GHIP_BLOCK), GHIP_BLOCK, 0, st>>>(
-    t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<double>(ctx->gp),
-    P<double>(ctx->gq), sg, nt, P<int>(ctx->tg_gas) + lo, b, K, P<double>(ctx->hpart), counter);
+  k_hydro<<<nbk * nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp),
+                                     P<double>(ctx->gq), nt, nsub, P<int>(ctx->tg_gas) + lo, b, K,
+                                     P<double>(ctx->hpart), counter);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[11], st));
   k_hydro_combine<<<cdiv(nt, 256), 256, 0, st>>>(

@@ -690,7 +690,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
       k_inverse_perm<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(ctx->st.perm),
                                                     P<int>(ctx->st.iperm));
-      GCHK(ghip_build_segments(ctx, ctx->st, false));
+      GCHK(ghip_sph_fill_nodes(ctx, false));
       GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
       GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
       const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
@@ -735,6 +735,7 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
     k_node_level<false, false><<<cdiv(t.nelem, 256), 256, 0, st>>>(
       t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
   HIPCHK(hipGetLastError());
+  GCHK(ghip_sph_fill_nodes(ctx, true));
   HIPCHK(hipEventRecord(ctx->ev[9], st));
   return GHIP_OK;
 }

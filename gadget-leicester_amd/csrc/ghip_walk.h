@@ -480,27 +480,90 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   W.nint = 0;
   unsigned int steps = 0;
 
-  // this wavefront owns segments sub, sub+S, sub+2S, ...  (advancing two segments at once, both
-  // loads in flight together, was measured: no gain, +9 VGPRs -- the walk is issue-bound)
-  SegCursor A;
-  int skipA = 0;
-  A.kseg = sub;
-  const int stride = sg.nsub;
-  bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid, W,
-                                               skipA, steps);
-  while(liveA)
+  if(MODE != GHIP_WALK_EWALD)
     {
-      v16i HA;
-      d_issue_load(hot, A.e, HA);
-      d_wait1(HA);
-      steps++;
-      A.e = __builtin_amdgcn_readfirstlane(
-        d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
-      if(A.e >= A.s1)
+      // this wavefront owns segments sub, sub+S, sub+2S, ...  (advancing two segments at once was
+      // measured for the Newtonian walk: no gain, +9 VGPRs -- that walk is issue-bound)
+      SegCursor A;
+      int skipA = 0;
+      A.kseg = sub;
+      const int stride = sg.nsub;
+      bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                   W, skipA, steps);
+      while(liveA)
         {
-          A.kseg += stride;
-          liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                  W, skipA, steps);
+          v16i HA;
+          d_issue_load(hot, A.e, HA);
+          d_wait1(HA);
+          steps++;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          if(A.e >= A.s1)
+            {
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipA, steps);
+            }
+        }
+    }
+  else
+    {
+      // Ewald walk: bound by the table gathers (12 x 16 B per lane and interaction through the
+      // vector-memory path).  Two of the wavefront's segments advance together (slot A: sub,
+      // sub+2S, ...; slot B: sub+S, sub+3S, ...) so that two elements' gathers are in flight.
+      SegCursor A, B;
+      int skipA = 0, skipB = 0;
+      A.kseg = sub;
+      B.kseg = sub + sg.nsub;
+      const int stride = 2 * sg.nsub;
+      bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                   W, skipA, steps);
+      bool liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                   W, skipB, steps);
+      while(liveA && liveB)
+        {
+          v16i HA, HB;
+          d_issue_load(hot, A.e, HA);
+          d_issue_load(hot, B.e, HB);
+          d_wait2(HA, HB);
+          steps += 2;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          B.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
+          if(A.e >= A.s1)
+            {
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipA, steps);
+            }
+          if(B.e >= B.s1)
+            {
+              B.kseg += stride;
+              liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipB, steps);
+            }
+        }
+      if(liveB)
+        {
+          A = B;
+          skipA = skipB;
+          liveA = true;
+        }
+      while(liveA)
+        {
+          v16i HA;
+          d_issue_load(hot, A.e, HA);
+          d_wait1(HA);
+          steps++;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          if(A.e >= A.s1)
+            {
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipA, steps);
+            }
         }
     }
 

@@ -546,7 +546,16 @@ def test_shard_pack_unpack_reproduces_the_unsharded_step():
                 B.F_DTENTROPY, B.F_MAXSIGNALVEL):
         want = ref.get_field(fid)
         for fp in ctxs:
-            assert np.array_equal(fp.get_field(fid), want), fid
+            got = fp.get_field(fid)
+            # every rank ends with the same bits as every other rank ...
+            assert np.array_equal(got, ctxs[0].get_field(fid)), fid
+            # ... and agrees with the unsharded run: integers exactly, fp64 to summation order
+            # (how many wavefronts share a bucket, hence the grouping of the partial sums,
+            # depends on the launch size)
+            if got.dtype == np.int32:
+                assert np.array_equal(got, want), fid
+            else:
+                assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), fid
     assert sum(fp.stats()["grav_targets"] for fp in ctxs) == pr.n
 
 
