@@ -8,10 +8,14 @@
 // then loops over it.  Here one wavefront serves a bucket of 64 targets that are consecutive
 // along the space-filling curve and walks the GAS tree's pre-order element list with a
 // wave-uniform index: a node is descended if ANY lane's search sphere overlaps it (the
-// reference's own node test, per lane), candidate gas records arrive as 64-byte scalar loads,
-// and each lane applies the reference's exact acceptance test (r2 < h_i^2, or r2 < h_i^2 ||
-// r2 < h_j^2 for pairs) before accumulating.  Neighbour SETS are geometric, so they are
-// identical to the reference's; only the summation order follows this tree's depth-first order.
+// reference's own node test, per lane).  Node records (64 B) arrive through the scalar path; the
+// candidate gas records of a node with <= 64 particles are fetched with one coalesced vector
+// load into LDS and read back as broadcast ds_reads (one memory latency per 64 candidates), and
+// each lane applies the reference's exact acceptance test (r2 < h_i^2, or r2 < h_i^2 ||
+// r2 < h_j^2 for pairs) before accumulating.  When the target list is short, several wavefronts
+// share a bucket, each taking every n-th candidate batch; their partial sums are added in fixed
+// order.  Neighbour SETS are geometric, so they are identical to the reference's; only the
+// summation order differs.
 #include <hipcub/hipcub.hpp>
 
 #include "ghip_internal.h"
@@ -28,7 +32,6 @@
 #define GAMMA (7. / 5.)  // allvars.h:64 (this fork: 7/5, not 5/3)
 #define GAMMA_MINUS1 (GAMMA - 1)
 #define FACT1 0.366025403785  // allvars.h:310
-#define LEAF_DIRECT 16        // nodes with <= this many particles are swept as a flat range
 
 struct BoxK
 {

@@ -105,6 +105,29 @@ __device__ __forceinline__ unsigned long long d_peano21(int x, int y, int z)
   return k;
 }
 
+// the leading `levels` (<= 10) digits of the same key
+__device__ __forceinline__ unsigned int d_peano_top(int x, int y, int z, int levels)
+{
+  int perm0 = 0, perm1 = 1, perm2 = 2, f0 = 0, f1 = 0, f2 = 0;
+  unsigned int k = 0;
+  for(int b = GHIP_BITS - 1; b >= GHIP_BITS - levels; b--)
+    {
+      int bit[3] = {(x >> b) & 1, (y >> b) & 1, (z >> b) & 1};
+      int w0 = bit[perm0] ^ f0, w1 = bit[perm1] ^ f1, w2 = bit[perm2] ^ f2;
+      int local = w0 * 4 + w1 * 2 + w2;
+      k = (k << 3) | c_ph_base[local];
+      int p[3] = {perm0, perm1, perm2}, f[3] = {f0, f1, f2};
+      int a0 = c_ph_perm[local][0], a1 = c_ph_perm[local][1], a2 = c_ph_perm[local][2];
+      perm0 = p[a0];
+      perm1 = p[a1];
+      perm2 = p[a2];
+      f0 = f[a0] ^ c_ph_flip[local][0];
+      f1 = f[a1] ^ c_ph_flip[local][1];
+      f2 = f[a2] ^ c_ph_flip[local][2];
+    }
+  return k;
+}
+
 __global__ void k_peano_from_pos(int n, const double *__restrict__ x, const double *__restrict__ y,
                                  const double *__restrict__ z, double cx, double cy, double cz,
                                  double fac, unsigned long long *__restrict__ key,
@@ -217,16 +240,25 @@ __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ sk
       c = (i + 1 < n) ? d_common_levels(skey[i], skey[i + 1]) : -1;
       cpl[i] = c;
     }
-  // deepest node level of the tree = largest shared-digit count (one atomic per wavefront)
+  // deepest node level of the tree = largest shared-digit count: one same-address access per
+  // block of 1024 (per wavefront they cost 45 us at 5e5 particles)
   for(int off = 32; off > 0; off >>= 1)
     {
       int o = __shfl_xor(c, off, 64);
       c = o > c ? o : c;
     }
-  // (read first: after the first few wavefronts nobody raises the maximum any more, and 8192
-  // same-address atomics cost 70 us)
-  if((threadIdx.x & 63) == 0 && c > *(volatile int *) maxlevel)
-    atomicMax(maxlevel, c);
+  __shared__ int wmax[16];
+  if((threadIdx.x & 63) == 0)
+    wmax[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if(threadIdx.x == 0)
+    {
+      int nw = (blockDim.x + 63) >> 6;
+      for(int w = 1; w < nw; w++)
+        c = wmax[w] > c ? wmax[w] : c;
+      if(c > *(volatile int *) maxlevel)
+        atomicMax(maxlevel, c);
+    }
 }
 
 __global__ void k_node_counts(int n, const int *__restrict__ cpl, int *__restrict__ cnt)
@@ -496,6 +528,64 @@ __global__ void k_mark_active(int nact, const int *__restrict__ act, const int *
 // ---------------------------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------------------------
+// ---- two-step key sort: a radix sort of (top 32 key bits, index) pairs -- half the passes and
+// two thirds of the bytes of a 64-bit sort -- then the rare runs of equal top bits (particles
+// closer than 2^-11 of the domain) are ordered by their full keys in place
+__global__ void k_key_hi(int n, int shift, const unsigned long long *__restrict__ key,
+                         unsigned int *__restrict__ hi)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    hi[i] = (unsigned int) (key[i] >> shift);
+}
+
+__global__ void k_gather_keys(int n, const int *__restrict__ perm,
+                              const unsigned long long *__restrict__ key,
+                              unsigned long long *__restrict__ skey)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    skey[s] = key[perm[s]];
+}
+
+// one thread per run start: insertion sort by (full key, index) -- the order a stable 64-bit
+// sort gives.  Runs longer than `maxrun` are left alone and reported (the caller falls back).
+__global__ void k_fix_runs(int n, int maxrun, unsigned long long *__restrict__ skey,
+                           int *__restrict__ perm, int *__restrict__ longest)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  unsigned int h = (unsigned int) (skey[s] >> 31);
+  if(s > 0 && (unsigned int) (skey[s - 1] >> 31) == h)
+    return;   // not a run start
+  int e = s + 1;
+  while(e < n && (unsigned int) (skey[e] >> 31) == h)
+    e++;
+  int len = e - s;
+  if(len == 1)
+    return;
+  if(len > maxrun)
+    {
+      atomicMax(longest, len);
+      return;
+    }
+  for(int a = s + 1; a < e; a++)
+    {
+      unsigned long long k = skey[a];
+      int p = perm[a];
+      int b = a - 1;
+      while(b >= s && (skey[b] > k || (skey[b] == k && perm[b] > p)))
+        {
+          skey[b + 1] = skey[b];
+          perm[b + 1] = perm[b];
+          b--;
+        }
+      skey[b + 1] = k;
+      perm[b + 1] = p;
+    }
+}
+
 __global__ void k_iota_tree(int n, int *__restrict__ a)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,83 +606,219 @@ static int cub_tmp(ghip_ctx *ctx, size_t bytes)
   return ghip_ensure(ctx, ctx->cubtmp, bytes + 256);
 }
 
-static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
-                     const double *z, const double *m, const double *aux_host_order, bool grav)
+// ---------------------------------------------------------------------------------------------
+// tree construction driver.  The build is latency-bound (dozens of launches of a few us each),
+// so the steps are arranged for few launches and ONE host round trip for both trees:
+//   sort (gravity tree)  ->  gas order by compaction  ->  node counts of both trees  ->  read
+//   back {maxlevel, nnodes} of both  ->  emit + moments of both  ->  curve order of the targets
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather5(int n, const int *__restrict__ perm, const double *__restrict__ x,
+                          const double *__restrict__ y, const double *__restrict__ z,
+                          const double *__restrict__ m, const double *__restrict__ a,
+                          double *__restrict__ ox, double *__restrict__ oy,
+                          double *__restrict__ oz, double *__restrict__ om,
+                          double *__restrict__ oa, int *__restrict__ iperm)
 {
-  t.n = n;
-  t.nnodes = 0;
-  t.nelem = n;
-  t.built = false;
-  if(n == 0)
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  int i = perm[s];
+  ox[s] = x[i];
+  oy[s] = y[i];
+  oz[s] = z[i];
+  om[s] = m[i];
+  oa[s] = a[i];
+  iperm[i] = s;
+}
+
+// out[0] = deepest level, out[1] = number of nodes, out[2] = longest unsorted key run
+__global__ void k_tree_info(int n, const int *__restrict__ nb, const int *__restrict__ cnt,
+                            const int *__restrict__ dinfo, int *__restrict__ out)
+{
+  out[0] = dinfo[0];
+  out[1] = nb[n - 1] + cnt[n - 1];
+  out[2] = dinfo[1];
+}
+
+// gas flags in gravity-tree order (gas = host index below ngas)
+__global__ void k_gas_flags(int n, int ngas, const int *__restrict__ perm, int *__restrict__ flag)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    flag[s] = perm[s] < ngas ? 1 : 0;
+}
+
+// the gas tree's sorted order is the gravity tree's with the other types removed (same keys,
+// same tie order)
+__global__ void k_gas_compact(int n, int ngas, const int *__restrict__ perm,
+                              const unsigned long long *__restrict__ skey,
+                              const int *__restrict__ rank, int *__restrict__ gperm,
+                              unsigned long long *__restrict__ gskey)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  int i = perm[s];
+  if(i < ngas)
     {
-      t.built = true;
-      return GHIP_OK;
+      int r = rank[s];
+      gperm[r] = i;
+      gskey[r] = skey[s];
     }
+}
+
+// flags of the curve-ordered gravity-tree indices, and their compaction to gas-tree indices
+__global__ void k_gas_flags_ph(int n, int ngas, const int *__restrict__ phorder,
+                               const int *__restrict__ perm, int *__restrict__ flag)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if(j < n)
+    flag[j] = perm[phorder[j]] < ngas ? 1 : 0;
+}
+
+__global__ void k_gas_compact_ph(int n, int ngas, const int *__restrict__ phorder,
+                                 const int *__restrict__ perm, const int *__restrict__ rank,
+                                 const int *__restrict__ pos, int *__restrict__ gphorder)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if(j >= n)
+    return;
+  int s = phorder[j];
+  if(perm[s] < ngas)
+    gphorder[pos[j]] = rank[s];
+}
+
+__global__ void k_peano_hi(int n, int levels, const double *__restrict__ x,
+                           const double *__restrict__ y, const double *__restrict__ z, double cx,
+                           double cy, double cz, double fac, unsigned int *__restrict__ hi,
+                           int *__restrict__ idx)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  hi[i] = d_peano_top((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac),
+                      (int) ((z[i] - cz) * fac), levels);
+  idx[i] = i;
+}
+
+static int exclusive_sum(ghip_ctx *ctx, const int *in, int *out, int n)
+{
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, n, ctx->stream));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, in, out, n, ctx->stream));
+  return GHIP_OK;
+}
+
+static int *tree_dinfo(ghip_ctx *ctx, bool gas)
+{
+  return reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 48) + (gas ? 2 : 0);
+}
+
+// Morton keys of the gravity tree's particles, sorted -> t.skey, t.perm
+static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
+                       const double *z, bool wide)
+{
   hipStream_t st = ctx->stream;
   GCHK(ghip_ensure(ctx, t.key, (size_t) n * 8));
   GCHK(ghip_ensure(ctx, t.skey, (size_t) n * 8));
   GCHK(ghip_ensure(ctx, t.idx, (size_t) n * 4));
   GCHK(ghip_ensure(ctx, t.perm, (size_t) n * 4));
-  GCHK(ghip_ensure(ctx, t.cpl, (size_t) n * 4));
-  GCHK(ghip_ensure(ctx, t.cnt, (size_t) n * 4));
-  GCHK(ghip_ensure(ctx, t.nb, (size_t) (n + 1) * 4));
-
+  GCHK(ghip_ensure(ctx, t.phkey, (size_t) n * 8));
   double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);  // DomainFac, domain.c:2012
   k_morton_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, x, y, z, ctx->corner[0], ctx->corner[1],
                                                   ctx->corner[2], fac,
                                                   P<unsigned long long>(t.key), P<int>(t.idx));
   HIPCHK(hipGetLastError());
-
   size_t tb = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, P<unsigned long long>(t.key),
-                                            P<unsigned long long>(t.skey), P<int>(t.idx),
-                                            P<int>(t.perm), n, 0, 63, st));
-  GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, P<unsigned long long>(t.key),
-                                            P<unsigned long long>(t.skey), P<int>(t.idx),
-                                            P<int>(t.perm), n, 0, 63, st));
+  if(!wide)
+    {
+      // top 32 key bits first, then the (rare) runs of equal top bits by their full keys
+      unsigned int *hi_in = P<unsigned int>(t.phkey), *hi_out = hi_in + n;
+      k_key_hi<<<cdiv(n, 256), 256, 0, st>>>(n, 31, P<unsigned long long>(t.key), hi_in);
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(t.idx),
+                                                P<int>(t.perm), n, 0, 32, st));
+      GCHK(cub_tmp(ctx, tb));
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(t.idx),
+                                                P<int>(t.perm), n, 0, 32, st));
+      k_gather_keys<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), P<unsigned long long>(t.key),
+                                                  P<unsigned long long>(t.skey));
+      k_fix_runs<<<cdiv(n, 256), 256, 0, st>>>(n, 32, P<unsigned long long>(t.skey),
+                                               P<int>(t.perm), tree_dinfo(ctx, false) + 1);
+      HIPCHK(hipGetLastError());
+    }
+  else
+    {
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, P<unsigned long long>(t.key),
+                                                P<unsigned long long>(t.skey), P<int>(t.idx),
+                                                P<int>(t.perm), n, 0, 63, st));
+      GCHK(cub_tmp(ctx, tb));
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, P<unsigned long long>(t.key),
+                                                P<unsigned long long>(t.skey), P<int>(t.idx),
+                                                P<int>(t.perm), n, 0, 63, st));
+    }
+  return GHIP_OK;
+}
 
-  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
-  int *dmaxlev = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 48);
-  HIPCHK(hipMemsetAsync(dmaxlev, 0, 4, st));
-  k_prefix_levels<<<cdiv(n, 256), 256, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl),
-                                                dmaxlev);
+// gas tree order out of the gravity tree's; leaves rank[] (gravity-tree index -> gas-tree index)
+// in ctx->dtgt_b for the curve order below
+static int gas_order_from_gravity_tree(ghip_ctx *ctx)
+{
+  TreeDev &g = ctx->gt, &t = ctx->st;
+  int n = ctx->n, ng = ctx->ngas;
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, t.skey, (size_t) ng * 8));
+  GCHK(ghip_ensure(ctx, t.perm, (size_t) ng * 4));
+  GCHK(ghip_ensure(ctx, ctx->dtgt_a, (size_t) n * 4 + 16));
+  GCHK(ghip_ensure(ctx, ctx->dtgt_b, (size_t) n * 4 + 16));
+  k_gas_flags<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.perm), P<int>(ctx->dtgt_a));
+  GCHK(exclusive_sum(ctx, P<int>(ctx->dtgt_a), P<int>(ctx->dtgt_b), n));
+  k_gas_compact<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.perm),
+                                              P<unsigned long long>(g.skey), P<int>(ctx->dtgt_b),
+                                              P<int>(t.perm), P<unsigned long long>(t.skey));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+// common prefix levels, nodes per particle and their scan; {maxlevel, nnodes, longest run} -> hout
+static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout)
+{
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, t.cpl, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.cnt, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, t.nb, (size_t) (n + 1) * 4));
+  int *dinfo = tree_dinfo(ctx, gas);
+  k_prefix_levels<<<cdiv(n, 1024), 1024, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl),
+                                                  dinfo);
   k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), P<int>(t.cnt));
   HIPCHK(hipGetLastError());
-  tb = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
-  GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, P<int>(t.cnt), P<int>(t.nb), n, st));
-  int last_nb = 0, last_cnt = 0, maxlev = 0;
-  HIPCHK(hipMemcpyAsync(&maxlev, dmaxlev, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&last_nb, P<int>(t.nb) + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&last_cnt, P<int>(t.cnt) + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  t.nnodes = last_nb + last_cnt;
-  t.nelem = n + t.nnodes;
-  t.maxlevel = maxlev < GHIP_BITS ? maxlev : GHIP_BITS;
+  GCHK(exclusive_sum(ctx, P<int>(t.cnt), P<int>(t.nb), n));
+  k_tree_info<<<1, 1, 0, st>>>(n, P<int>(t.nb), P<int>(t.cnt), dinfo, hout);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
 
+// element list + moments.  Sorted particle data goes to ox,oy,oz,om,oa; iperm is filled too.
+static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const double *x,
+                     const double *y, const double *z, const double *m, const double *aux,
+                     double *ox, double *oy, double *oz, double *om, double *oa, bool grav)
+{
+  hipStream_t st = ctx->stream;
+  t.n = n;
+  t.nnodes = hinfo[1];
+  t.nelem = n + t.nnodes;
+  t.maxlevel = hinfo[0] < GHIP_BITS ? hinfo[0] : GHIP_BITS;
   GCHK(ghip_ensure(ctx, t.xm, (size_t) t.nelem * sizeof(double4)));
   GCHK(ghip_ensure(ctx, t.cl, (size_t) t.nelem * sizeof(double4)));
   GCHK(ghip_ensure(ctx, t.lk, (size_t) t.nelem * sizeof(int4)));
   GCHK(ghip_ensure(ctx, t.aux, (size_t) t.nelem * sizeof(double)));
-
-  // sorted particle data into the staging buffer: x,y,z,m,aux
-  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 5 * sizeof(double)));
-  double *sx = P<double>(ctx->stage), *sy = sx + n, *sz = sy + n, *sm = sz + n, *sa = sm + n;
-  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), x, sx);
-  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), y, sy);
-  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), z, sz);
-  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), m, sm);
-  k_gather_f64<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), aux_host_order, sa);
-  HIPCHK(hipGetLastError());
-
+  k_gather5<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
+                                          P<int>(t.iperm));
   k_emit_elements<<<cdiv(n, 256), 256, 0, st>>>(
-    n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), sx, sy,
-    sz, sm, sa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
+    n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
+    oz, om, oa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
     P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
   HIPCHK(hipGetLastError());
-
   for(int L = t.maxlevel; L >= 0; L--)
     {
       if(grav)
@@ -603,36 +829,57 @@ static int build_one(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const do
           t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
     }
   HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
 
-  // Peano-Hilbert order of the (tree-order) particles: the order in which targets are bucketed
-  GCHK(ghip_ensure(ctx, t.phkey, (size_t) n * 8));
-  GCHK(ghip_ensure(ctx, t.phorder, (size_t) n * 4));
+// Peano-Hilbert order of the tree-order particles: the order in which targets are bucketed.
+// The order only has to make 64 consecutive targets compact, so the sort runs on the leading
+// ceil(log8 n) + 3 digits of the key (at most 10: they fit a 32-bit sort).
+static int curve_order(ghip_ctx *ctx)
+{
+  TreeDev &g = ctx->gt, &t = ctx->st;
+  int n = ctx->n, ng = ctx->ngas;
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, g.phorder, (size_t) n * 4));
+  if(ng > 0)
+    GCHK(ghip_ensure(ctx, t.phorder, (size_t) ng * 4));
   if(getenv("GHIP_TARGET_ORDER") && !strcmp(getenv("GHIP_TARGET_ORDER"), "morton"))
-    k_iota_tree<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.phorder));
-  else
     {
-      k_peano_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, sx, sy, sz, ctx->corner[0],
-                                                     ctx->corner[1], ctx->corner[2], fac,
-                                                     P<unsigned long long>(t.key), P<int>(t.idx));
-      // the order only has to make 64 consecutive targets compact: sort on the leading
-      // ceil(log8 n) + 3 digits of the key (the radix sort's cost is its number of 8-bit passes)
-      int levels = 3;
-      for(long long m = n; m > 1; m >>= 3)
-        levels++;
-      if(levels > GHIP_BITS)
-        levels = GHIP_BITS;
-      int begin_bit = 63 - 3 * levels;
-      size_t tb2 = 0;
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, P<unsigned long long>(t.key),
-                                                P<unsigned long long>(t.phkey), P<int>(t.idx),
-                                                P<int>(t.phorder), n, begin_bit, 63, st));
-      GCHK(cub_tmp(ctx, tb2));
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb2, P<unsigned long long>(t.key),
-                                                P<unsigned long long>(t.phkey), P<int>(t.idx),
-                                                P<int>(t.phorder), n, begin_bit, 63, st));
+      k_iota_tree<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(g.phorder));
+      if(ng > 0)
+        k_iota_tree<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(t.phorder));
+      HIPCHK(hipGetLastError());
+      return GHIP_OK;
     }
+  int levels = 3;
+  for(long long m = n; m > 1; m >>= 3)
+    levels++;
+  if(levels > 10)
+    levels = 10;
+  double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);
+  unsigned int *hi_in = P<unsigned int>(g.phkey), *hi_out = hi_in + n;
+  k_peano_hi<<<cdiv(n, 256), 256, 0, st>>>(n, levels, P<double>(ctx->sx), P<double>(ctx->sy),
+                                           P<double>(ctx->sz), ctx->corner[0], ctx->corner[1],
+                                           ctx->corner[2], fac, hi_in, P<int>(g.idx));
   HIPCHK(hipGetLastError());
-  t.built = true;
+  // (a 32-bit hipcub sort with begin_bit != 0 mis-sorts on this ROCm: the digits sit at bit 0)
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(g.idx),
+                                            P<int>(g.phorder), n, 0, 3 * levels, st));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(g.idx),
+                                            P<int>(g.phorder), n, 0, 3 * levels, st));
+  if(ng > 0)
+    {
+      // the gas targets in the same order: compaction of the list above (rank[] = dtgt_b)
+      GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
+      int *flag = P<int>(ctx->dflags), *pos = P<int>(ctx->dtgt_a);
+      k_gas_flags_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm), flag);
+      GCHK(exclusive_sum(ctx, flag, pos, n));
+      k_gas_compact_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm),
+                                                     P<int>(ctx->dtgt_b), pos, P<int>(t.phorder));
+      HIPCHK(hipGetLastError());
+    }
   return GHIP_OK;
 }
 
@@ -646,6 +893,14 @@ __global__ void k_soft_of_type(int n, const int *__restrict__ type, double s0, d
   out[i] = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
 }
 
+static void tree_reset(TreeDev &t, int n)
+{
+  t.n = n;
+  t.nnodes = 0;
+  t.nelem = n;
+  t.built = (n == 0);
+}
+
 int ghip_tree_build_impl(ghip_ctx *ctx)
 {
   int n = ctx->n, ng = ctx->ngas;
@@ -653,43 +908,70 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   const double *x = P<double>(ctx->f[GHIP_F_POS]);
   const double *y = x + n, *z = y + n;
   const double *m = P<double>(ctx->f[GHIP_F_MASS]);
+  const double *h = P<double>(ctx->f[GHIP_F_HSML]);
   HIPCHK(hipEventRecord(ctx->ev[0], st));
+  tree_reset(ctx->gt, n);
+  tree_reset(ctx->st, ng);
+  ctx->lists_dirty = true;
+  ctx->stats.tree_nodes = ctx->stats.gastree_nodes = 0;
+  if(n == 0)
+    {
+      HIPCHK(hipEventRecord(ctx->ev[1], st));
+      return GHIP_OK;
+    }
+  if(!ctx->pinned)
+    {
+      HIPCHK(hipHostMalloc(&ctx->pinned, 256, hipHostMallocDefault));
+      ctx->pinned_cap = 256;
+    }
+  int *hinfo = reinterpret_cast<int *>(ctx->pinned);  // [0..2] gravity tree, [4..6] gas tree
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
 
   // per-particle softening in host order (aux of the gravity tree's particle elements)
-  GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) (n > 0 ? n : 1) * 8));
-  GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) (n > 0 ? n : 1) * 8));
+  GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) n * 8));
   double *tmp_soft = P<double>(ctx->soldacc);  // scratch until the first gravity call
-  if(n > 0)
-    k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
-                                                 ctx->soft[1], ctx->soft[2], ctx->soft[3],
-                                                 ctx->soft[4], ctx->soft[5], tmp_soft);
-  GCHK(build_one(ctx, ctx->gt, n, x, y, z, m, tmp_soft, true));
-  if(n > 0)
+  k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
+                                               ctx->soft[1], ctx->soft[2], ctx->soft[3],
+                                               ctx->soft[4], ctx->soft[5], tmp_soft);
+
+  bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
+  for(;;)
     {
-      GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
-      k_inverse_perm<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->gt.perm), P<int>(ctx->gt.iperm));
-      GCHK(ghip_build_segments(ctx, ctx->gt, true));
-      GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
-      GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
-      GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
-      // the staging buffer still holds sorted x,y,z,m,soft from build_one
-      double *sx = P<double>(ctx->stage);
-      HIPCHK(hipMemcpyAsync(ctx->sx.p, sx, (size_t) n * 8, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(ctx->sy.p, sx + n, (size_t) n * 8, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(ctx->sz.p, sx + 2 * (size_t) n, (size_t) n * 8,
-                            hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(ctx->ssoft.p, sx + 4 * (size_t) n, (size_t) n * 8,
-                            hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemsetAsync(tree_dinfo(ctx, false), 0, 16, st));
+      GCHK(sort_by_key(ctx, ctx->gt, n, x, y, z, wide));
+      GCHK(count_nodes(ctx, ctx->gt, n, false, hinfo));
+      if(ng > 0)
+        {
+          GCHK(gas_order_from_gravity_tree(ctx));
+          GCHK(count_nodes(ctx, ctx->st, ng, true, hinfo + 4));
+        }
+      HIPCHK(hipStreamSynchronize(st));   // the one host round trip of the build
+      if(wide || hinfo[2] == 0)
+        break;
+      wide = true;   // strongly clustered input: long runs of equal top key bits, sort full keys
     }
 
+  GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 5 * sizeof(double)));
+  GCHK(emit_tree(ctx, ctx->gt, n, hinfo, x, y, z, m, tmp_soft, P<double>(ctx->sx),
+                 P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->stage),
+                 P<double>(ctx->ssoft), true));
+  ctx->gt.built = true;
+  GCHK(ghip_build_segments(ctx, ctx->gt, true));
+  GCHK(curve_order(ctx));
+
   // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml
-  const double *h = P<double>(ctx->f[GHIP_F_HSML]);
-  GCHK(build_one(ctx, ctx->st, ng, x, y, z, m, h, false));
   if(ng > 0)
     {
       GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
-      k_inverse_perm<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(ctx->st.perm),
-                                                    P<int>(ctx->st.iperm));
+      double *s = P<double>(ctx->stage);
+      GCHK(emit_tree(ctx, ctx->st, ng, hinfo + 4, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
+                     s + 3 * (size_t) ng, s + 4 * (size_t) ng, false));
+      ctx->st.built = true;
       GCHK(ghip_sph_fill_nodes(ctx, false));
       GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
       GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
@@ -705,7 +987,6 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   ctx->stats.tree_nodes = ctx->gt.nnodes;
   ctx->stats.gastree_nodes = ctx->st.nnodes;
-  ctx->lists_dirty = true;
   return GHIP_OK;
 }
 

@@ -127,6 +127,48 @@ def test_gravity_clustered_and_unequal_softenings():
     assert relerr(fp.get_field(B.F_GRAVACCEL), d) < 1e-10
 
 
+@pytest.mark.parametrize("clump", [20, 90])
+def test_tight_clumps_sort_paths(clump):
+    """Particles closer than 2^-11 of the domain share the top 32 key bits: short runs are ordered
+    by the in-place fix-up, a run of more than 32 makes the build fall back to the 63-bit sort.
+    Either way the cells, counts and forces are the insertion tree's."""
+    B = bindings()
+    ic = ics.make_plummer(3000, gas_fraction=0.3)
+    rng = np.random.default_rng(3)
+    # a clump of gas and one of collisionless particles, each inside one level-12 cell (so all
+    # its keys share the top 32 bits) but far wider than the 1e-3 x softening below which the
+    # reference picks sub-cells at random (forcetree.c:219-232, not reproduced on the device)
+    corner, _, dlen = O.domain_extent(ic["pos"])
+    cell = dlen / 4096
+    for first in (5, ic["ngas"] + 5):
+        c = corner + (np.floor((ic["pos"][first] - corner) / cell) + 0.5) * cell
+        ic["pos"][first:first + clump] = c + 0.2 * cell * (rng.random((clump, 3)) - 0.5)
+    assert np.array_equal(O.domain_extent(ic["pos"])[0], corner)
+    pr = Problem(ic=ic, periodic=0, soft_frac=0.0004)
+    fp = pr.device()
+    pr.device_tree(fp)
+    T = pr.oracle_tree()
+    assert fp.stats()["tree_nodes"] == T.numnodes
+    d = fp.tree_dump(0)
+    nodes = d["lk"][:, 1] < 0
+    od = T.dump()
+    assert np.array_equal(np.sort(d["cl"][nodes][:, 3]), np.sort(od["len"]))
+    tg = _all(pr.n)
+    fp.gravity(pr.g_grav(0.5), B.WALK_NEWTON)
+    oacc, ocost = T.gravity(pr.o_grav(0.5), tg, np.zeros(pr.n))
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), ocost)
+    assert relerr(fp.get_field(B.F_GRAVACCEL), oacc) < TOL
+    # the gas tree (derived from the gravity tree's order) finds the brute-force neighbours
+    h = 0.1 * cell
+    pos = ic["pos"]
+    for i in (5, 7):
+        lst, cnt = fp.ngb_treefind(pos[i], h, 0, 0, pr.box)
+        got = np.sort(lst)
+        assert cnt == len(lst)
+        want = np.where(np.sum((pos[:pr.ngas] - pos[i]) ** 2, axis=1) < h * h)[0]
+        assert np.array_equal(got, want)
+
+
 def test_shortrange_walk_parity():
     B = bindings()
     pr = Problem(ng=12, gas=True, periodic=1)
