@@ -400,16 +400,22 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
     }
   int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
-  if(k.periodic)
-    k_grav_walk<MODE, true><<<blocks, bsize, 0, ctx->stream>>>(
-      t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-      P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
-      P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan);
+#define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
+  k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, 0, ctx->stream>>>(                                 \
+    t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
+    P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),        \
+    P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan)
+  // (the Ewald walk has no softening rule: one variant)
+  const bool uneq = (MODE != GHIP_WALK_EWALD) && k.unequal;
+  if(k.periodic && uneq)
+    GHIP_LAUNCH_WALK(true, true);
+  else if(k.periodic)
+    GHIP_LAUNCH_WALK(true, false);
+  else if(uneq)
+    GHIP_LAUNCH_WALK(false, true);
   else
-    k_grav_walk<MODE, false><<<blocks, bsize, 0, ctx->stream>>>(
-      t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-      P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),
-      P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan);
+    GHIP_LAUNCH_WALK(false, false);
+#undef GHIP_LAUNCH_WALK
 }
 
 static void launch_walk_any(ghip_ctx *ctx, int walk, const TreeDev &t, const WalkSeg &sg,

@@ -202,10 +202,28 @@ __device__ __forceinline__ double d_nearest1(double x, double boxsize, double bo
   return (fabs(x) > boxhalf) ? x - copysign(boxsize, x) : x;
 }
 
+// the same under the execution mask (compare, sign transfer, subtract: 3 vector instructions
+// where the select form takes 5; the empty asm keeps the compiler from if-converting it back)
+__device__ __forceinline__ double d_nearest1_masked(double x, double boxsize, double boxhalf)
+{
+  if(fabs(x) > boxhalf)
+    {
+      x -= copysign(boxsize, x);
+      asm volatile("" : "+v"(x));
+    }
+  return x;
+}
+
+__device__ __forceinline__ bool d_any(bool pred)
+{
+  return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+}
+
 // One element of the list for all 64 lanes.  H = hot record (already in SGPRs).  OWNED = false
 // replays only the opening decision (ancestor of a segment).  Returns the next element index
-// (wave-uniform).
-template <int MODE, bool PERIODIC, bool OWNED>
+// (wave-uniform).  The per-lane decisions are kept as lane masks (act / open / far / drop) and
+// combined with mask arithmetic, which the compiler maps to the scalar unit.
+template <int MODE, bool PERIODIC, bool UNEQUAL, bool OWNED>
 __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                                               const WalkCold *__restrict__ cold, const GravK &p,
                                               const float *__restrict__ srtab,
@@ -222,20 +240,19 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   double dx = ex - W.pos_x, dy = ey - W.pos_y, dz = ez - W.pos_z;
   if(MODE == GHIP_WALK_EWALD || PERIODIC)
     {
-      // (a wave-uniform "does any lane wrap?" branch per axis was measured slower than the
-      // straight compare+select: 14.1 vs 12.8 ms at c2)
-      dx = d_nearest1(dx, p.boxsize, p.boxhalf);
-      dy = d_nearest1(dy, p.boxsize, p.boxhalf);
-      dz = d_nearest1(dz, p.boxsize, p.boxhalf);
+      dx = d_nearest1_masked(dx, p.boxsize, p.boxhalf);
+      dy = d_nearest1_masked(dy, p.boxsize, p.boxhalf);
+      dz = d_nearest1_masked(dz, p.boxsize, p.boxhalf);
     }
   const double r2 = dx * dx + dy * dy + dz * dz;
   double h = W.h_i, h2 = W.h2;
-  bool interact = act;
+  bool interact;
 
   if(pidx >= 0)
     {
       next = e + 1;
-      if(MODE != GHIP_WALK_EWALD && p.unequal)
+      interact = act;
+      if(MODE != GHIP_WALK_EWALD && UNEQUAL)
         {
           if(h < aux)
             {
@@ -246,32 +263,31 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
     }
   else
     {
-      bool open = false;
       // first part of the criterion needs only the hot record (forcetree.c:2074-2091)
-      bool far_enough = false;   // passed the distance test, box test still pending
-      if(act)
-        {
-          if(p.theta != 0)
-            open = (len2 > r2 * p.theta * p.theta);
-          else
-            {
-              open = (mlen2 > r2 * r2 * W.aold);
-              far_enough = !open;
-            }
-        }
+      const bool relative = (p.theta == 0);
+      bool gt;
+      if(relative)
+        gt = (mlen2 > r2 * r2 * W.aold);
+      else
+        gt = (len2 > r2 * p.theta * p.theta);
+      bool open = act && gt;
+      bool far = act && !gt && relative;   // passed the distance test, box test still pending
+      bool drop = false;                   // short-range walk: whole cell beyond the cut-off
       // the cold half (cell centre, len) is needed for:
       //  * the "inside the 1.2*len box" rule of the relative criterion (forcetree.c:2093-2104):
       //    only possible when r2 < 3.63*len^2 (centre of mass inside the cell, box half-width
       //    0.6*len: |x - s| < (0.6 + 0.5)*sqrt(3)*len), tested conservatively with 4*len^2
+      //    (formed exactly by adding 2 to the exponent, on the scalar unit)
       //  * the short-range cut-off pruning and the Ewald override
+      const double len2x4 = __hiloint2double(H[11] + 0x00200000, H[10]);
       bool need_cold;
       if(MODE == GHIP_WALK_NEWTON)
-        need_cold = far_enough && (r2 < 4.0 * len2);
+        need_cold = far && (r2 < len2x4);
       else if(MODE == GHIP_WALK_SHORTRANGE)
-        need_cold = act && ((r2 > p.rcut2) || (far_enough && (r2 < 4.0 * len2)));
+        need_cold = act && ((r2 > p.rcut2) || (far && (r2 < len2x4)));
       else
-        need_cold = act && (open || (far_enough && (r2 < 4.0 * len2)));
-      if(__any(need_cold))
+        need_cold = open || (far && (r2 < len2x4));
+      if(d_any(need_cold))
         {
           v16i C;
           d_issue_load(cold, e, C);
@@ -292,23 +308,19 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                       d1 = d_nearest1(d1, p.boxsize, p.boxhalf);
                       d2 = d_nearest1(d2, p.boxsize, p.boxhalf);
                     }
-                  if(fabs(d0) > eff || fabs(d1) > eff || fabs(d2) > eff)
-                    {
-                      interact = false;
-                      open = false;
-                      far_enough = false;
-                      my_skip = skip;
-                    }
+                  drop = (fabs(d0) > eff || fabs(d1) > eff || fabs(d2) > eff);
                 }
+              open = open && !drop;
+              far = far && !drop;
             }
-          if(far_enough)
+          if(far)
             open = (fabs(cx - W.pos_x) < len06) && (fabs(cy - W.pos_y) < len06) &&
                    (fabs(cz - W.pos_z) < len06);
           if(MODE == GHIP_WALK_EWALD)
             {
               // forcetree.c:3039-3088: the correction is smooth, so an "open" verdict is
               // overridden unless the cell straddles the half-box or is large
-              if(act && open)
+              if(open)
                 {
                   double u0 = d_nearest1(cx - W.pos_x, p.boxsize, p.boxhalf);
                   double u1 = d_nearest1(cy - W.pos_y, p.boxsize, p.boxhalf);
@@ -319,11 +331,11 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                 }
             }
         }
-      if(interact)
+      if(MODE != GHIP_WALK_EWALD && UNEQUAL)
         {
-          if(MODE != GHIP_WALK_EWALD && p.unequal && !open)
+          // forcetree.c:2108-2124
+          if(act && !drop && !open)
             {
-              // forcetree.c:2108-2124
               double ms = fabs(aux);
               if(h < ms)
                 {
@@ -333,12 +345,11 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                     open = true;
                 }
             }
-          if(open)
-            interact = false;
-          else
-            my_skip = skip;
         }
-      next = __any(open) ? e + 1 : skip;
+      interact = act && !drop && !open;
+      if(interact || drop)
+        my_skip = skip;
+      next = d_any(open) ? e + 1 : skip;
     }
 
   if(OWNED && interact)
@@ -401,7 +412,7 @@ struct SegCursor
 
 // enter segment `c.kseg`: replay the ancestors, position the cursor at the first element any lane
 // still needs.  Returns false when the slot has no segment left.
-template <int MODE, bool PERIODIC>
+template <int MODE, bool PERIODIC, bool UNEQUAL>
 __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const WalkSeg &sg,
                                                 const WalkHot *__restrict__ hot,
                                                 const WalkCold *__restrict__ cold, const GravK &p,
@@ -421,7 +432,7 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
           v16i H;
           d_issue_load(hot, ea, H);
           d_wait1(H);
-          d_walk_element<MODE, PERIODIC, false>(ea, H, cold, p, srtab, ewtab, W, my_skip);
+          d_walk_element<MODE, PERIODIC, UNEQUAL, false>(ea, H, cold, p, srtab, ewtab, W, my_skip);
           steps++;
         }
       int first = d_wave_min_i32(my_skip);   // every lane below an accepted ancestor: jump
@@ -437,7 +448,7 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
 // Grid: a multiple of 8 blocks; the block index is remapped so that each XCD (blocks are dealt
 // round-robin over the 8 XCDs) works through ONE contiguous eighth of the buckets: neighbouring
 // buckets read the same deep tree nodes, which then stay in that XCD's 4 MB L2.
-template <int MODE, bool PERIODIC>
+template <int MODE, bool PERIODIC, bool UNEQUAL>
 __global__ void __launch_bounds__(GHIP_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == GHIP_WALK_EWALD ? 4 : GHIP_WALK_WAVES, 8)))
 k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restrict__ cold,
             WalkSeg sg, int nt, const int *__restrict__ tgt, const double *__restrict__ tx,
@@ -488,7 +499,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       int skipA = 0;
       A.kseg = sub;
       const int stride = sg.nsub;
-      bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
                                                    W, skipA, steps);
       while(liveA)
         {
@@ -497,11 +508,11 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
           d_wait1(HA);
           steps++;
           A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
           if(A.e >= A.s1)
             {
               A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
                                                       valid, W, skipA, steps);
             }
         }
@@ -516,9 +527,9 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       A.kseg = sub;
       B.kseg = sub + sg.nsub;
       const int stride = 2 * sg.nsub;
-      bool liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
                                                    W, skipA, steps);
-      bool liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
+      bool liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
                                                    W, skipB, steps);
       while(liveA && liveB)
         {
@@ -528,19 +539,19 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
           d_wait2(HA, HB);
           steps += 2;
           A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
           B.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
           if(A.e >= A.s1)
             {
               A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
                                                       valid, W, skipA, steps);
             }
           if(B.e >= B.s1)
             {
               B.kseg += stride;
-              liveB = d_enter_segment<MODE, PERIODIC>(B, stride, sg, hot, cold, p, srtab, ewtab,
+              liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL>(B, stride, sg, hot, cold, p, srtab, ewtab,
                                                       valid, W, skipB, steps);
             }
         }
@@ -557,11 +568,11 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
           d_wait1(HA);
           steps++;
           A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
           if(A.e >= A.s1)
             {
               A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC>(A, stride, sg, hot, cold, p, srtab, ewtab,
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
                                                       valid, W, skipA, steps);
             }
         }

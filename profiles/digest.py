@@ -1,0 +1,88 @@
+"""Digest of profiles/collect.sh's output into the committed summaries:
+  profiles/<tag>_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats summary of the bench command
+  profiles/<tag>_walk_pmc.json           per-kernel PMC means for the two gravity walks and the SPH kernels
+  profiles/grav_walk_traffic.json        HBM bytes per relative-criterion launch of k_grav_walk<NEWTON>
+                                         (bench.py reads this for roofline.traffic)
+Usage: python profiles/digest.py gpurun_out/prof_r01 r01
+The first launch of each gravity walk in a bench run is the Barnes-Hut pass that seeds OldAcc
+(accel.c:61-68); it is left out so the numbers describe the relative-criterion launches the bench times.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+KERNELS = {
+    "k_grav_walk<NEWTON>": "void k_grav_walk<0, true>",
+    "k_grav_walk<EWALD>": "void k_grav_walk<2, true>",
+    "k_density": "k_density(",
+    "k_hydro": "k_hydro(",
+}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"),
+                os.path.join(here, "%s_bench_kernel_stats.csv" % tag))
+    counters = {k: {} for k in KERNELS}
+    for f in sorted(glob.glob(os.path.join(src, "pmc*", "p_counter_collection.csv"))):
+        seen = {}
+        acc = {}
+        for row in csv.DictReader(open(f)):
+            for label, prefix in KERNELS.items():
+                if row["Kernel_Name"].startswith(prefix):
+                    key = (label, row["Counter_Name"])
+                    seen[key] = seen.get(key, 0) + 1
+                    if label.startswith("k_grav_walk") and seen[key] == 1:
+                        continue   # the Barnes-Hut launch
+                    a = acc.setdefault(key, [0.0, 0, 0.0])
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+                    a[2] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        for (label, cname), a in acc.items():
+            counters[label][cname] = {"mean": a[0] / a[1], "launches": a[1],
+                                      "mean_duration_ns": a[2] / a[1]}
+    derived = {}
+    for label, c in counters.items():
+        d = {}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            d["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024
+        if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
+            d["valu_active_fraction_of_wave_cycles"] = (c["SQ_ACTIVE_INST_VALU"]["mean"] /
+                                                        c["SQ_WAVE_CYCLES"]["mean"])
+        if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            d["wait_inst_fraction_of_wave_cycles"] = (c["SQ_WAIT_INST_ANY"]["mean"] /
+                                                      c["SQ_WAVE_CYCLES"]["mean"])
+        if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+            # 256 CUs x 4 SIMDs, one VALU instruction issued per SIMD per cycle at best
+            d["valu_issue_fraction_of_peak"] = (c["SQ_INSTS_VALU"]["mean"] /
+                                                (c["GRBM_GUI_ACTIVE"]["mean"] * 1024))
+        if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            d["mean_resident_waves_per_simd"] = (c["SQ_WAVE_CYCLES"]["mean"] /
+                                                 (c["GRBM_GUI_ACTIVE"]["mean"] * 1024))
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            d["l2_hit_rate"] = c["TCC_HIT_sum"]["mean"] / (c["TCC_HIT_sum"]["mean"] +
+                                                          c["TCC_MISS_sum"]["mean"])
+        if "GRBM_GUI_ACTIVE" in c:
+            d["mean_clock_GHz"] = c["GRBM_GUI_ACTIVE"]["mean"] / c["GRBM_GUI_ACTIVE"]["mean_duration_ns"]
+        derived[label] = d
+    out = {"note": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 3 "
+                   "--warmup 1 --no-cpu-baseline (profiles/collect.sh); relative-criterion launches "
+                   "only; FETCH_SIZE/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts half the "
+                   "bytes of wide reads, MI355X_MICROARCH.md HBM section)",
+           "counters": counters, "derived": derived}
+    json.dump(out, open(os.path.join(here, "%s_walk_pmc.json" % tag), "w"), indent=1)
+    c = counters["k_grav_walk<NEWTON>"]
+    traffic = {"ng": 64, "kernel": "k_grav_walk<NEWTON>",
+               "FETCH_SIZE_KB": c["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB": c["WRITE_SIZE"]["mean"],
+               "hbm_bytes_per_launch": derived["k_grav_walk<NEWTON>"]["hbm_bytes_per_launch"],
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md",
+               "source": "profiles/%s_walk_pmc.json" % tag}
+    json.dump(traffic, open(os.path.join(here, "grav_walk_traffic.json"), "w"), indent=1)
+    print(json.dumps(derived, indent=1))
+
+
+main()
