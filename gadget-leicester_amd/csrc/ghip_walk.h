@@ -92,6 +92,21 @@ __device__ __forceinline__ void d_issue_load(const T *__restrict__ base, int e, 
   const T *p = reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
   asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(R) : "s"(p) : "memory");
 }
+// touch record `e` so that its cache line is on its way into the scalar cache: one dword into a
+// scratch SGPR, which stays reserved until d_wait_touch (the load writes it asynchronously)
+template <class T>
+__device__ __forceinline__ void d_touch(const T *__restrict__ base, int e, int &scratch)
+{
+  unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
+  unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
+  const T *p = reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(scratch) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void d_wait_touch(v16i &A, int &s1, int &s2)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(s1), "+s"(s2) : : "memory");
+}
 __device__ __forceinline__ void d_wait1(v16i &A)
 {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
@@ -214,15 +229,17 @@ __device__ __forceinline__ double d_nearest1_masked(double x, double boxsize, do
   return x;
 }
 
-__device__ __forceinline__ bool d_any(bool pred)
-{
-  return __builtin_amdgcn_ballot_w64(pred) != 0ull;
-}
+// Lane masks.  Every per-lane decision of the walk is held as a 64-bit mask in scalar registers:
+// a vector compare writes its result there directly (ballot of a compare), the masks are combined
+// on the scalar unit, a vote is a scalar compare with zero, and a mask becomes the execution mask
+// of a conditional block without any vector instruction (inverse ballot).
+typedef unsigned long long lmask;
+#define D_BAL(cond) __builtin_amdgcn_ballot_w64(cond)
+#define D_LANE(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 
 // One element of the list for all 64 lanes.  H = hot record (already in SGPRs).  OWNED = false
 // replays only the opening decision (ancestor of a segment).  Returns the next element index
-// (wave-uniform).  The per-lane decisions are kept as lane masks (act / open / far / drop) and
-// combined with mask arithmetic, which the compiler maps to the scalar unit.
+// (wave-uniform).  All 64 lanes are active here (lanes without a target carry my_skip = INT_MAX).
 template <int MODE, bool PERIODIC, bool UNEQUAL, bool OWNED>
 __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                                               const WalkCold *__restrict__ cold, const GravK &p,
@@ -234,7 +251,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   const double mlen2 = d_f64(H, 4), len2 = d_f64(H, 5);
   const int skip = H[12], pidx = H[13];
   const double aux = d_f64(H, 7);
-  const bool act = (e >= my_skip);
+  const lmask act = D_BAL(e >= my_skip);
   int next;
 
   double dx = ex - W.pos_x, dy = ey - W.pos_y, dz = ez - W.pos_z;
@@ -246,7 +263,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
     }
   const double r2 = dx * dx + dy * dy + dz * dz;
   double h = W.h_i, h2 = W.h2;
-  bool interact;
+  lmask interact;
 
   if(pidx >= 0)
     {
@@ -264,15 +281,21 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   else
     {
       // first part of the criterion needs only the hot record (forcetree.c:2074-2091)
-      const bool relative = (p.theta == 0);
-      bool gt;
-      if(relative)
-        gt = (mlen2 > r2 * r2 * W.aold);
+      lmask gt, rel;
+      if(p.theta == 0)
+        {
+          gt = D_BAL(mlen2 > r2 * r2 * W.aold);
+          rel = ~0ull;
+          asm volatile("" : "+s"(gt));   // keep the two criteria in separate (uniform) branches
+        }
       else
-        gt = (len2 > r2 * p.theta * p.theta);
-      bool open = act && gt;
-      bool far = act && !gt && relative;   // passed the distance test, box test still pending
-      bool drop = false;                   // short-range walk: whole cell beyond the cut-off
+        {
+          gt = D_BAL(len2 > r2 * p.theta * p.theta);
+          rel = 0ull;
+        }
+      lmask open = act & gt;
+      lmask far = act & ~gt & rel;   // passed the distance test, box test still pending
+      lmask drop = 0;                // short-range walk: whole cell beyond the cut-off
       // the cold half (cell centre, len) is needed for:
       //  * the "inside the 1.2*len box" rule of the relative criterion (forcetree.c:2093-2104):
       //    only possible when r2 < 3.63*len^2 (centre of mass inside the cell, box half-width
@@ -280,79 +303,83 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
       //    (formed exactly by adding 2 to the exponent, on the scalar unit)
       //  * the short-range cut-off pruning and the Ewald override
       const double len2x4 = __hiloint2double(H[11] + 0x00200000, H[10]);
-      bool need_cold;
-      if(MODE == GHIP_WALK_NEWTON)
-        need_cold = far && (r2 < len2x4);
-      else if(MODE == GHIP_WALK_SHORTRANGE)
-        need_cold = act && ((r2 > p.rcut2) || (far && (r2 < len2x4)));
-      else
-        need_cold = open || (far && (r2 < len2x4));
-      if(d_any(need_cold))
+      const lmask boxcand = far & D_BAL(r2 < len2x4);
+      lmask cutcand = 0;
+      if(MODE == GHIP_WALK_SHORTRANGE)
+        cutcand = act & D_BAL(r2 > p.rcut2);
+      lmask need_cold = boxcand;
+      if(MODE == GHIP_WALK_SHORTRANGE)
+        need_cold |= cutcand;
+      if(MODE == GHIP_WALK_EWALD)
+        need_cold |= open;
+      if(need_cold != 0)
         {
           v16i C;
           d_issue_load(cold, e, C);
           d_wait1(C);
           const double cx = d_f64(C, 0), cy = d_f64(C, 1), cz = d_f64(C, 2), len = d_f64(C, 3);
           const double len06 = d_f64(C, 4);
+          const double c0 = cx - W.pos_x, c1 = cy - W.pos_y, c2 = cz - W.pos_z;
           if(MODE == GHIP_WALK_SHORTRANGE)
             {
               // forcetree.c:2598-2632: whole cell beyond the cut-off -> drop the branch.  The
               // reference tests this BEFORE the opening criterion.
-              if(act && r2 > p.rcut2)
+              if(cutcand != 0)
                 {
                   double eff = p.rcut + 0.5 * len;
-                  double d0 = cx - W.pos_x, d1 = cy - W.pos_y, d2 = cz - W.pos_z;
+                  double d0 = c0, d1 = c1, d2 = c2;
                   if(PERIODIC)
                     {
                       d0 = d_nearest1(d0, p.boxsize, p.boxhalf);
                       d1 = d_nearest1(d1, p.boxsize, p.boxhalf);
                       d2 = d_nearest1(d2, p.boxsize, p.boxhalf);
                     }
-                  drop = (fabs(d0) > eff || fabs(d1) > eff || fabs(d2) > eff);
+                  drop = cutcand &
+                         (D_BAL(fabs(d0) > eff) | D_BAL(fabs(d1) > eff) | D_BAL(fabs(d2) > eff));
                 }
-              open = open && !drop;
-              far = far && !drop;
+              open &= ~drop;
+              far &= ~drop;
             }
-          if(far)
-            open = (fabs(cx - W.pos_x) < len06) && (fabs(cy - W.pos_y) < len06) &&
-                   (fabs(cz - W.pos_z) < len06);
+          if(far != 0)
+            open |= far & D_BAL(fabs(c0) < len06) & D_BAL(fabs(c1) < len06) &
+                    D_BAL(fabs(c2) < len06);
           if(MODE == GHIP_WALK_EWALD)
             {
               // forcetree.c:3039-3088: the correction is smooth, so an "open" verdict is
               // overridden unless the cell straddles the half-box or is large
-              if(open)
+              if(open != 0 && !(len > 0.20 * p.boxsize))
                 {
-                  double u0 = d_nearest1(cx - W.pos_x, p.boxsize, p.boxhalf);
-                  double u1 = d_nearest1(cy - W.pos_y, p.boxsize, p.boxhalf);
-                  double u2 = d_nearest1(cz - W.pos_z, p.boxsize, p.boxhalf);
+                  double u0 = d_nearest1(c0, p.boxsize, p.boxhalf);
+                  double u1 = d_nearest1(c1, p.boxsize, p.boxhalf);
+                  double u2 = d_nearest1(c2, p.boxsize, p.boxhalf);
                   double lim = 0.5 * (p.boxsize - len);
-                  open = (fabs(u0) > lim) || (fabs(u1) > lim) || (fabs(u2) > lim) ||
-                         (len > 0.20 * p.boxsize);
+                  open &= D_BAL(fabs(u0) > lim) | D_BAL(fabs(u1) > lim) | D_BAL(fabs(u2) > lim);
                 }
             }
         }
       if(MODE != GHIP_WALK_EWALD && UNEQUAL)
         {
           // forcetree.c:2108-2124
-          if(act && !drop && !open)
+          const double ms = fabs(aux);
+          const lmask up = act & ~drop & ~open & D_BAL(h < ms);
+          if(up != 0)
             {
-              double ms = fabs(aux);
-              if(h < ms)
+              if(D_LANE(up))
                 {
                   h = ms;
-                  h2 = h * h;
-                  if(r2 < h2 && aux < 0)
-                    open = true;
+                  h2 = ms * ms;
                 }
+              if(aux < 0)
+                open |= up & D_BAL(r2 < ms * ms);
             }
         }
-      interact = act && !drop && !open;
-      if(interact || drop)
+      interact = act & ~drop & ~open;
+      if(D_LANE(interact | drop))
         my_skip = skip;
-      next = d_any(open) ? e + 1 : skip;
+      next = (open != 0) ? e + 1 : skip;
     }
 
-  if(OWNED && interact)
+  if(OWNED && D_LANE(interact))
     {
       if(MODE == GHIP_WALK_EWALD)
         {
@@ -499,23 +526,34 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       int skipA = 0;
       A.kseg = sub;
       const int stride = sg.nsub;
-      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                   W, skipA, steps);
+      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab,
+                                                            ewtab, valid, W, skipA, steps);
+      // Both possible successors of an element -- e+1 (descend / next particle) and its skip
+      // link -- are touched as soon as its record has arrived, so the next step's 64-byte load
+      // finds its line in the scalar cache instead of paying the L2 latency of the pointer
+      // chase.  (the list carries one padding record: e+1 and skip are always readable)
+      int t1 = 0, t2 = 0;
       while(liveA)
         {
           v16i HA;
           d_issue_load(hot, A.e, HA);
-          d_wait1(HA);
+          d_wait_touch(HA, t1, t2);
+          d_touch(hot, A.e + 1, t1);
+          d_touch(hot, HA[12], t2);
           steps++;
           A.e = __builtin_amdgcn_readfirstlane(
             d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
           if(A.e >= A.s1)
             {
               A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
-                                                      valid, W, skipA, steps);
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab,
+                                                               ewtab, valid, W, skipA, steps);
             }
         }
+      {
+        v16i Z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        d_wait_touch(Z, t1, t2);   // nothing in flight when the scratch registers are given up
+      }
     }
   else
     {

@@ -15,8 +15,8 @@ import shutil
 import sys
 
 KERNELS = {
-    "k_grav_walk<NEWTON>": "void k_grav_walk<0, true>",
-    "k_grav_walk<EWALD>": "void k_grav_walk<2, true>",
+    "k_grav_walk<NEWTON>": "void k_grav_walk<0, true",
+    "k_grav_walk<EWALD>": "void k_grav_walk<2, true",
     "k_density": "k_density(",
     "k_hydro": "k_hydro(",
 }
