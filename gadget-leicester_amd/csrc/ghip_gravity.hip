@@ -112,16 +112,19 @@ __global__ void k_pack_xyzm(int n, const double *__restrict__ x, const double *_
 
 // ---------------------------------------------------------------------------------------------
 // Ewald table (ewald_init / ewald_force, forcetree.c:4402-4527, 4727-4778): alpha = 2,
-// |n|,|h| <= 4, one octant of (EN+1)^3 points at x = 0.5*(i,j,k)/EN, scaled by 1/BoxSize^2
+// |n|,|h| <= 4, one octant of (EN+1)^3 points at x = 0.5*(i,j,k)/EN, scaled by 1/BoxSize^2.
+// Only the x component is tabulated: fcorry[i][j][k] = fcorrx[j][i][k] and fcorrz[i][j][k] =
+// fcorrx[k][j][i] by the symmetry of the cubic lattice sums (equal up to the rounding of the
+// summation order, ~1e-16), see d_ewald_interp.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_ewald_table(double inv_box2, EwEntry *__restrict__ tab)
+__global__ void k_ewald_table(double inv_box2, double *__restrict__ tab)
 {
   const int E1 = GHIP_EN + 1;
   int nidx = blockIdx.x * blockDim.x + threadIdx.x;
   if(nidx >= E1 * E1 * E1)
     return;
   int i = nidx / (E1 * E1), j = (nidx / E1) % E1, k = nidx % E1;
-  double f0 = 0, f1 = 0, f2 = 0;
+  double f0 = 0;
   if(i + j + k != 0)
     {
       const double alpha = 2.0;
@@ -130,8 +133,6 @@ __global__ void k_ewald_table(double inv_box2, EwEntry *__restrict__ tab)
       double r2 = x0 * x0 + x1 * x1 + x2 * x2;
       double rr = r2 * sqrt(r2);
       f0 += x0 / rr;
-      f1 += x1 / rr;
-      f2 += x2 / rr;
       for(int n0 = -4; n0 <= 4; n0++)
         for(int n1 = -4; n1 <= 4; n1++)
           for(int n2 = -4; n2 <= 4; n2++)
@@ -141,8 +142,6 @@ __global__ void k_ewald_table(double inv_box2, EwEntry *__restrict__ tab)
               double val = erfc(alpha * r) + 2 * alpha * r / sqrt(M_PI) * exp(-alpha * alpha * r * r);
               double w = val / (r * r * r);
               f0 -= d0 * w;
-              f1 -= d1 * w;
-              f2 -= d2 * w;
             }
       for(int h0 = -4; h0 <= 4; h0++)
         for(int h1 = -4; h1 <= 4; h1++)
@@ -155,13 +154,10 @@ __global__ void k_ewald_table(double inv_box2, EwEntry *__restrict__ tab)
                   double val = 2.0 / ((double) hh) * exp(-M_PI * M_PI * hh / (alpha * alpha)) *
                                sin(2 * M_PI * hdotx);
                   f0 -= h0 * val;
-                  f1 -= h1 * val;
-                  f2 -= h2 * val;
                 }
             }
     }
-  EwEntry out = {f0 * inv_box2, f1 * inv_box2, f2 * inv_box2};
-  tab[nidx] = out;
+  tab[nidx] = f0 * inv_box2;
 }
 
 extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
@@ -170,9 +166,9 @@ extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ewald_init: bad BoxSize");
   const int E1 = GHIP_EN + 1;
   const int nt = E1 * E1 * E1;
-  GCHK(ghip_ensure(ctx, ctx->ewtab, (size_t) nt * sizeof(EwEntry)));
+  GCHK(ghip_ensure(ctx, ctx->ewtab, (size_t) (nt + 2) * sizeof(double)));
   k_ewald_table<<<cdiv(nt, 64), 64, 0, ctx->stream>>>(1.0 / (BoxSize * BoxSize),
-                                                      P<EwEntry>(ctx->ewtab));
+                                                      P<double>(ctx->ewtab));
   HIPCHK(hipGetLastError());
   ctx->ew_box = BoxSize;
   return GHIP_OK;
@@ -184,12 +180,19 @@ extern "C" int ghip_ewald_get_table(ghip_ctx *ctx, double *host)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ewald_get_table: table not initialised");
   const int E1 = GHIP_EN + 1;
   const size_t nt = (size_t) E1 * E1 * E1;
-  std::vector<double> tmp(nt * 4);
-  HIPCHK(hipMemcpyAsync(tmp.data(), ctx->ewtab.p, nt * 24, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<double> tmp(nt);
+  HIPCHK(hipMemcpyAsync(tmp.data(), ctx->ewtab.p, nt * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for(size_t q = 0; q < nt; q++)
-    for(int c = 0; c < 3; c++)
-      host[c * nt + q] = tmp[3 * q + c];
+  // the three tables of the reference (fcorrx, fcorry, fcorrz) out of the one stored
+  for(int i = 0; i < E1; i++)
+    for(int j = 0; j < E1; j++)
+      for(int k = 0; k < E1; k++)
+        {
+          size_t q = ((size_t) i * E1 + j) * E1 + k;
+          host[q] = tmp[q];
+          host[nt + q] = tmp[((size_t) j * E1 + i) * E1 + k];
+          host[2 * nt + q] = tmp[((size_t) k * E1 + j) * E1 + i];
+        }
   return GHIP_OK;
 }
 
@@ -391,7 +394,7 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   long long nthreads = (long long) plan.nwaves * 64;
   // one wavefront per workgroup: wavefronts of a bucket finish at very different times, and a
   // 256-thread workgroup would hold its four slots until the slowest one is done
-  int bsize = GHIP_BLOCK;
+  int bsize = 64;
   if(getenv("GHIP_WALK_BLOCK"))
     {
       int v = atoi(getenv("GHIP_WALK_BLOCK"));
@@ -403,7 +406,7 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, 0, ctx->stream>>>(                                 \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
-    P<float>(ctx->srtab), P<EwEntry>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),        \
+    P<float>(ctx->srtab), P<double>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),        \
     P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan)
   // (the Ewald walk has no softening rule: one variant)
   const bool uneq = (MODE != GHIP_WALK_EWALD) && k.unequal;

@@ -90,7 +90,7 @@ struct ghip_ctx
   int plan_nb[3] = {-1, -1, -1}, plan_ns[3] = {-1, -1, -1}, plan_cur[3] = {0, 0, 0};
 
   // ewald
-  DevBuf ewtab;   // double4[(EN+1)^3]: fx,fy,fz,0 scaled by 1/Box^2
+  DevBuf ewtab;   // double[(EN+1)^3]: fcorrx scaled by 1/Box^2 (y, z by symmetry)
   double ew_box = 0;
   DevBuf srtab;   // float[NTAB]
   bool srtab_ready = false;

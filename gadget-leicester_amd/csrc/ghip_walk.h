@@ -70,12 +70,16 @@ struct __attribute__((aligned(64))) WalkCold
 
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// one grid point of the Ewald correction table: 24 bytes, no padding (the look-up is bound by
-// the bytes the 8 corner gathers move through the vector-memory path)
-struct EwEntry
+// two neighbouring entries of the Ewald table (8-byte aligned; the hardware takes 16-byte
+// global loads at any dword address)
+struct __attribute__((aligned(8))) EwPair
 {
-  double x, y, z;
+  double lo, hi;
 };
+__device__ __forceinline__ EwPair d_ldpair(const double *p)
+{
+  return *reinterpret_cast<const EwPair *>(p);
+}
 
 __device__ __forceinline__ double d_f64(const v16i &v, int i)
 {
@@ -150,7 +154,7 @@ __device__ __forceinline__ double d_grav_fac(double mass, double r2, double h, d
 }
 
 // trilinear Ewald look-up, forcetree.c:3097-3170.  tab: double4 (fx,fy,fz,0) per grid point.
-__device__ __forceinline__ void d_ewald_interp(const EwEntry *__restrict__ tab, double fac_intp,
+__device__ __forceinline__ void d_ewald_interp(const double *__restrict__ tab, double fac_intp,
                                                double dx, double dy, double dz, double &fx,
                                                double &fy, double &fz)
 {
@@ -190,15 +194,28 @@ __device__ __forceinline__ void d_ewald_interp(const EwEntry *__restrict__ tab, 
   double f3 = (1 - u) * (v) * (1 - w), f4 = (1 - u) * (v) * (w);
   double f5 = (u) * (1 - v) * (1 - w), f6 = (u) * (1 - v) * (w);
   double f7 = (u) * (v) * (1 - w), f8 = (u) * (v) * (w);
-  const EwEntry *b = tab + ((size_t) i * E1 + j) * E1 + k;
-  EwEntry t1 = b[0], t2 = b[1], t3 = b[E1], t4 = b[E1 + 1];
-  EwEntry t5 = b[E1 * E1], t6 = b[E1 * E1 + 1], t7 = b[E1 * E1 + E1], t8 = b[E1 * E1 + E1 + 1];
-  fx = sx * (t1.x * f1 + t2.x * f2 + t3.x * f3 + t4.x * f4 + t5.x * f5 + t6.x * f6 + t7.x * f7 +
-             t8.x * f8);
-  fy = sy * (t1.y * f1 + t2.y * f2 + t3.y * f3 + t4.y * f4 + t5.y * f5 + t6.y * f6 + t7.y * f7 +
-             t8.y * f8);
-  fz = sz * (t1.z * f1 + t2.z * f2 + t3.z * f3 + t4.z * f4 + t5.z * f5 + t6.z * f6 + t7.z * f7 +
-             t8.z * f8);
+  // one table serves the three components: by the cubic symmetry of the lattice sum
+  // fy(x,y,z) = fx(y,x,z) and fz(x,y,z) = fx(z,y,x), so tab holds fx only (2.2 MB instead of
+  // 6.6 MB: it stays in the 4 MB L2 of an XCD).  Two neighbouring entries along the last index
+  // come with one 16-byte load.  Weights: f1..f8 = W[a][b][c] for the corner (i+a, j+b, k+c).
+  const double *bx = tab + ((size_t) i * E1 + j) * E1 + k;
+  const double *by = tab + ((size_t) j * E1 + i) * E1 + k;
+  const double *bz = tab + ((size_t) k * E1 + j) * E1 + i;
+  const EwPair x00 = d_ldpair(bx), x01 = d_ldpair(bx + E1), x10 = d_ldpair(bx + E1 * E1),
+               x11 = d_ldpair(bx + E1 * E1 + E1);
+  const EwPair y00 = d_ldpair(by), y01 = d_ldpair(by + E1), y10 = d_ldpair(by + E1 * E1),
+               y11 = d_ldpair(by + E1 * E1 + E1);
+  const EwPair z00 = d_ldpair(bz), z01 = d_ldpair(bz + E1), z10 = d_ldpair(bz + E1 * E1),
+               z11 = d_ldpair(bz + E1 * E1 + E1);
+  // fx: rows (a,b), pair over c
+  fx = sx * (x00.lo * f1 + x00.hi * f2 + x01.lo * f3 + x01.hi * f4 + x10.lo * f5 + x10.hi * f6 +
+             x11.lo * f7 + x11.hi * f8);
+  // fy = sum T[j+b][i+a][k+c] W[a][b][c]: rows (b,a), pair over c
+  fy = sy * (y00.lo * f1 + y00.hi * f2 + y10.lo * f3 + y10.hi * f4 + y01.lo * f5 + y01.hi * f6 +
+             y11.lo * f7 + y11.hi * f8);
+  // fz = sum T[k+c][j+b][i+a] W[a][b][c]: rows (c,b), pair over a
+  fz = sz * (z00.lo * f1 + z10.lo * f2 + z01.lo * f3 + z11.lo * f4 + z00.hi * f5 + z10.hi * f6 +
+             z01.hi * f7 + z11.hi * f8);
 }
 
 // per-lane target state shared by both in-flight segments
@@ -244,7 +261,7 @@ template <int MODE, bool PERIODIC, bool UNEQUAL, bool OWNED>
 __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                                               const WalkCold *__restrict__ cold, const GravK &p,
                                               const float *__restrict__ srtab,
-                                              const EwEntry *__restrict__ ewtab, WalkLane &W,
+                                              const double *__restrict__ ewtab, WalkLane &W,
                                               int &my_skip)
 {
   const double ex = d_f64(H, 0), ey = d_f64(H, 1), ez = d_f64(H, 2), mass = d_f64(H, 3);
@@ -444,7 +461,7 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
                                                 const WalkHot *__restrict__ hot,
                                                 const WalkCold *__restrict__ cold, const GravK &p,
                                                 const float *__restrict__ srtab,
-                                                const EwEntry *__restrict__ ewtab, bool valid,
+                                                const double *__restrict__ ewtab, bool valid,
                                                 WalkLane &W, int &my_skip, unsigned int &steps)
 {
   while(c.kseg < sg.ns)
@@ -481,7 +498,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
             WalkSeg sg, int nt, const int *__restrict__ tgt, const double *__restrict__ tx,
             const double *__restrict__ ty, const double *__restrict__ tz,
             const double *__restrict__ tsoft, const double *__restrict__ toldacc, GravK p,
-            const float *__restrict__ srtab, const EwEntry *__restrict__ ewtab,
+            const float *__restrict__ srtab, const double *__restrict__ ewtab,
             double *__restrict__ pax, double *__restrict__ pay, double *__restrict__ paz,
             int *__restrict__ pcost, unsigned long long *__restrict__ counter, WalkPlan plan)
 {
