@@ -34,44 +34,65 @@ class ShardedForceStep:
             self._buf[key] = (mine, allb)
         return self._buf[key]
 
-    def exchange(self, group):
-        """all-gather this phase's per-target results; no-op for a single rank."""
+    def exchange_begin(self, group):
+        """pack this rank's slice and start the all-gather of one phase; returns a handle for
+        exchange_end (None for a single rank).  With the RCCL backend the collective runs
+        asynchronously on its own stream, so it overlaps whatever is launched before
+        exchange_end."""
         if self.world == 1:
-            return
+            return None
         per, _ = self.e.shard_count(group != GROUP_GRAVITY)
         if per == 0:
-            return
+            return None
         mine, allb = self._buffers(group, per)
-        self.e.shard_pack(group, mine.data_ptr())
+        self.e.shard_pack(group, mine.data_ptr())      # synchronises the library's stream
         on_gpu = self.device is not None and str(self.device).startswith("cuda")
+        work = None
         if on_gpu and self.dist.get_backend() == "gloo":
             # self-test configuration (several ranks sharing one GPU): stage through the host
             host_all = allb.cpu()
             self.dist.all_gather_into_tensor(host_all, mine.cpu())
             allb.copy_(host_all)
+        elif on_gpu:
+            work = self.dist.all_gather_into_tensor(allb, mine, async_op=True)
         else:
             self.dist.all_gather_into_tensor(allb, mine)
+        return (group, allb, work, on_gpu)
+
+    def exchange_end(self, handle):
+        if handle is None:
+            return
+        group, allb, work, on_gpu = handle
+        if work is not None:
+            work.wait()
         if on_gpu:
             import torch
             torch.cuda.synchronize()
         self.e.shard_unpack(group, allb.data_ptr(), self.world)
 
+    def exchange(self, group):
+        """all-gather this phase's per-target results; no-op for a single rank."""
+        self.exchange_end(self.exchange_begin(group))
+
     def step(self, tree_args, grav_params, dens_params, hydro_params, G, walks, has_gas=True):
-        """tree build -> gravity walks -> density -> hmax -> hydro, with the three exchanges."""
+        """tree build -> gravity walks -> density -> hmax -> hydro, with the three exchanges.
+        Nothing in the SPH phases reads the gravity results, so their all-gather is only
+        collected at the end of the step and runs underneath the density kernels."""
         e = self.e
         e.tree_build(*tree_args)
         for w in walks:
             e.gravity(grav_params, w)
-        self.exchange(GROUP_GRAVITY)
-        if hasattr(e, "gravity_finish_all"):
-            e.gravity_finish_all(G)    # OldAcc / G scaling for every particle, on every rank
-        else:
-            e.set_shard(0, 1)
-            e.gravity_finish(G)
-            e.set_shard(self.rank, self.world)
+        pending = self.exchange_begin(GROUP_GRAVITY)
         if has_gas:
             e.density(dens_params)
             self.exchange(GROUP_DENSITY)
             e.update_hmax()
             e.hydro(hydro_params)
             self.exchange(GROUP_HYDRO)
+        self.exchange_end(pending)
+        if hasattr(e, "gravity_finish_all"):
+            e.gravity_finish_all(G)    # OldAcc / G scaling for every particle, on every rank
+        else:
+            e.set_shard(0, 1)
+            e.gravity_finish(G)
+            e.set_shard(self.rank, self.world)
