@@ -60,13 +60,17 @@ __device__ __forceinline__ bool d_node_overlaps(const double4 c, double dist, do
 
 __device__ __forceinline__ double d_wrap(double d, const BoxK b)
 {
-  // density.c:838-851 / hydra.c:1251-1264
+  // density.c:838-851 / hydra.c:1251-1264: d > boxhalf -> d - box, d < -boxhalf -> d + box.
+  // Written as one compare on |d| and a subtraction of copysign(box, d) under the execution mask
+  // (the same IEEE operations; 2 vector instructions per axis in the common no-wrap case, the
+  // empty asm keeps the compiler from turning it back into compare+select chains)
   if(b.periodic)
     {
-      if(d > b.boxhalf)
-        d -= b.boxsize;
-      if(d < -b.boxhalf)
-        d += b.boxsize;
+      if(fabs(d) > b.boxhalf)
+        {
+          d -= copysign(b.boxsize, d);
+          asm volatile("" : "+v"(d));
+        }
     }
   return d;
 }
@@ -440,6 +444,20 @@ __global__ void k_dens_finalize(int nt, int nsub, const int *__restrict__ tgt,
   redo[ti] = again;
 }
 
+// workgroups a density / hydro launch should at least consist of (buckets are shared by up to
+// GHIP_MAXSUB workgroups to get there)
+static int ghip_sph_target_waves()
+{
+  static int v = -1;
+  if(v < 0)
+    {
+      v = 8192;
+      if(getenv("GHIP_SPH_WAVES") && atoi(getenv("GHIP_SPH_WAVES")) > 0)
+        v = atoi(getenv("GHIP_SPH_WAVES"));
+    }
+  return v;
+}
+
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
 {
   int per;
@@ -510,7 +528,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
       // wavefronts per bucket: enough of them to occupy the chip when the target list is short
       // (late h-iterations, one rank's share of a multi-GPU run); each takes every nsub-th batch
       const int nbk = (ncur + 63) / 64;
-      int nsub = (8192 + nbk - 1) / nbk;
+      int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
       nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
       k_density<<<nbk * nsub, 64, 0, st>>>(
         t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur, nsub, cur, hcur, b, P<double>(ctx->drho),
@@ -955,7 +973,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
             p->ComovingIntegrationOn, p->raw_dtentropy};
   HIPCHK(hipEventRecord(ctx->ev[10], st));
   const int nbk = (nt + 63) / 64;
-  int nsub = (8192 + nbk - 1) / nbk;
+  int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
   nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
   GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
   k_hydro<<<nbk * nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp),
