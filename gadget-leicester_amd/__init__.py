@@ -18,7 +18,7 @@ LIBGHIP = os.path.join(PKG_DIR, "libghip.so")
 LIBHOST = os.path.join(PKG_DIR, "libgadget_force.so")
 
 HIP_SOURCES = ["ghip_api.hip", "ghip_tree.hip", "ghip_gravity.hip", "ghip_sph.hip",
-               "ghip_shard.hip", "ghip_drift.hip"]
+               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 
@@ -39,7 +39,7 @@ def hipcc_path():
 def build(force=False, verbose=False):
     """Compile libghip.so (HIP, gfx950) and libgadget_force.so (host C mirror) in-tree."""
     hipcc = hipcc_path()
-    hdrs = [os.path.join(CSRC, "ghip_internal.h"), os.path.join(CSRC, "ghip_walk.h"),
+    hdrs = [os.path.join(CSRC, "ghip_internal.h"), os.path.join(CSRC, "ghip_walk.h"), os.path.join(CSRC, "ghip_timefac.h"),
             os.path.join(REPO_DIR, "include", "ghip.h")]
     objs = []
     procs = []

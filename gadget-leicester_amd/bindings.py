@@ -67,6 +67,17 @@ class DriftParams(C.Structure):
                 ("MinGasHsml", C.c_double), ("box_wrap", C.c_int), ("BoxSize", C.c_double)]
 
 
+class KickParams(C.Structure):
+    _fields_ = [("Ti_Current", C.c_int), ("Timebase_interval", C.c_double),
+                ("ComovingIntegrationOn", C.c_int), ("Time", C.c_double), ("hubble_a", C.c_double),
+                ("ErrTolIntAccuracy", C.c_double), ("CourantFac", C.c_double),
+                ("MaxSizeTimestep", C.c_double), ("MinSizeTimestep", C.c_double),
+                ("dt_displacement", C.c_double), ("SofteningTable", C.c_double * 6),
+                ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint),
+                ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double),
+                ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("grav_interactions", C.c_longlong), ("grav_targets", C.c_longlong),
                 ("ewald_interactions", C.c_longlong), ("dens_neighbours", C.c_longlong),
@@ -75,7 +86,8 @@ class Stats(C.Structure):
                 ("tree_nodes", C.c_int), ("gastree_nodes", C.c_int),
                 ("ms_tree", C.c_float), ("ms_grav", C.c_float), ("ms_ewald", C.c_float),
                 ("ms_dens", C.c_float), ("ms_hmax", C.c_float), ("ms_hydro", C.c_float),
-                ("grav_wave_steps", C.c_longlong), ("ewald_wave_steps", C.c_longlong)]
+                ("grav_wave_steps", C.c_longlong), ("ewald_wave_steps", C.c_longlong),
+                ("ms_kick", C.c_float)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -97,7 +109,8 @@ EXPORTS = [
     "ghip_update_hmax", "ghip_hydro", "ghip_density_evaluate", "ghip_ngb_treefind",
     "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
-    "ghip_drift", "ghip_gravity_finish_all"]
+    "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
+    "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick"]
 
 
 def lib():
@@ -141,6 +154,10 @@ def lib():
         L.ghip_stream.restype = vp
         L.ghip_sync.argtypes = [vp]
         L.ghip_drift.argtypes = [vp, C.POINTER(DriftParams)]
+        L.ghip_advance_timesteps.argtypes = [vp, C.POINTER(KickParams), vp, vp]
+        L.ghip_timestep_endrun_code.argtypes = [vp]
+        L.ghip_velocity_moments.argtypes = [vp, vp, vp, vp]
+        L.ghip_download_aos_kick.argtypes = [vp, vp, vp, C.POINTER(Layout)]
         L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ghip_shard_pack.argtypes = [vp, C.c_int, vp]
         L.ghip_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -275,6 +292,30 @@ class ForcePath:
             p.logTimeBegin, p.logTimeMax = float(log_time_begin), float(log_time_max)
             p.DriftTable, p.GravKickTable, p.HydroKickTable = [t.ctypes.data for t in self._tabs]
         self._chk(self.L.ghip_drift(self.h, C.byref(p)))
+
+    def advance_timesteps(self, params, kick_tables=None):
+        """ghip_advance_timesteps; returns (TimeBinCount[32], TimeBinCountSph[32]).  A timestep
+        failure raises GhipError with .endrun = the reference's endrun code."""
+        if kick_tables is not None:
+            self._ktabs = [np.ascontiguousarray(t, dtype=np.float64) for t in kick_tables]
+            params.GravKickTable, params.HydroKickTable = [t.ctypes.data for t in self._ktabs]
+        cnt = (C.c_longlong * 32)()
+        sph = (C.c_longlong * 32)()
+        rc = self.L.ghip_advance_timesteps(self.h, C.byref(params), cnt, sph)
+        if rc != 0:
+            try:
+                self._chk(rc)
+            except GhipError as e:
+                e.endrun = self.L.ghip_timestep_endrun_code(self.h)
+                raise
+        return np.array(cnt[:], dtype=np.int64), np.array(sph[:], dtype=np.int64)
+
+    def velocity_moments(self):
+        v2 = (C.c_double * 6)()
+        mm = (C.c_double * 6)()
+        cnt = (C.c_longlong * 6)()
+        self._chk(self.L.ghip_velocity_moments(self.h, v2, mm, cnt))
+        return np.array(v2[:]), np.array(mm[:]), np.array(cnt[:], dtype=np.int64)
 
     def density(self, params):
         self._chk(self.L.ghip_density(self.h, C.byref(params)))

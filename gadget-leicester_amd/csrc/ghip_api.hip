@@ -74,7 +74,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       delete ctx;
       return GHIP_ENODEVICE;
     }
-  for(int i = 0; i < 12; i++)
+  for(int i = 0; i < 16; i++)
     if(hipEventCreate(&ctx->ev[i]) != hipSuccess)
       {
         delete ctx;
@@ -89,7 +89,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       return GHIP_ENOMEM;
     }
   // make every event "recorded" so that elapsed-time queries never fault
-  for(int i = 0; i < 12; i++)
+  for(int i = 0; i < 16; i++)
     (void) hipEventRecord(ctx->ev[i], ctx->stream);
   (void) hipStreamSynchronize(ctx->stream);
   *out = ctx;
@@ -130,7 +130,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(ctx->pinned)
     (void) hipHostFree(ctx->pinned);
   if(ctx->ev_ready)
-    for(int i = 0; i < 12; i++)
+    for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
   if(ctx->stream)
     (void) hipStreamDestroy(ctx->stream);
@@ -475,6 +475,61 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
   return GHIP_OK;
 }
 
+__global__ void k_pack_i16(size_t n, char *__restrict__ rec, int stride, int off,
+                           const int *__restrict__ src)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    *reinterpret_cast<short *>(rec + i * (size_t) stride + off) = (short) src[i];
+}
+
+__global__ void k_pack_i32(size_t n, char *__restrict__ rec, int stride, int off,
+                           const int *__restrict__ src)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    *reinterpret_cast<int *>(rec + i * (size_t) stride + off) = src[i];
+}
+
+// results of ghip_advance_timesteps into the record images (timestep.c: P[].Vel, TimeBin,
+// Ti_begstep; SphP[].VelPred, Entropy, e.DtEntropy)
+extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay)
+{
+  if(!ctx || !lay)
+    return GHIP_EINVAL;
+  size_t n = (size_t) ctx->n, ng = (size_t) ctx->ngas;
+  if(n == 0)
+    return GHIP_OK;
+  if(!Pp || (ng > 0 && !Sp))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_download_aos_kick: null record pointers");
+  if(ctx->aosP.cap < n * lay->p_stride || (ng > 0 && ctx->aosS.cap < ng * lay->s_stride))
+    return ghip_fail(ctx, GHIP_EINVAL,
+                     "ghip_download_aos_kick: no device image (call ghip_upload_aos)");
+  hipStream_t st = ctx->stream;
+  void *ip = ctx->aosP.p, *is = ctx->aosS.p;
+  PACK64(n, ip, lay->p_stride, lay->p_vel, 3, GHIP_F_VEL);
+  if(lay->p_timebin >= 0)
+    k_pack_i16<<<cdiv((long long) n, 256), 256, 0, st>>>(n, (char *) ip, lay->p_stride,
+                                                         lay->p_timebin,
+                                                         P<int>(ctx->f[GHIP_F_TIMEBIN]));
+  if(lay->p_ti_begstep >= 0)
+    k_pack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(n, (char *) ip, lay->p_stride,
+                                                         lay->p_ti_begstep,
+                                                         P<int>(ctx->f[GHIP_F_TI_BEGSTEP]));
+  if(ng > 0)
+    {
+      PACK64(ng, is, lay->s_stride, lay->s_velpred, 3, GHIP_F_VELPRED);
+      PACK64(ng, is, lay->s_stride, lay->s_entropy, 1, GHIP_F_ENTROPY);
+      PACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
+    }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(Pp, ip, n * lay->p_stride, hipMemcpyDeviceToHost, st));
+  if(ng > 0)
+    HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // active list / shard / tree / stats
 // ---------------------------------------------------------------------------------------------
@@ -564,6 +619,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   S.ms_dens = el(6, 7);
   S.ms_hmax = el(8, 9);
   S.ms_hydro = el(10, 11);
+  S.ms_kick = el(12, 13);
   *out = S;
   return GHIP_OK;
 }

@@ -9,40 +9,7 @@
 // out per gas particle).
 #include "ghip_internal.h"
 
-#define GAMMA (7. / 5.)  // allvars.h:64
-
-struct DriftK
-{
-  int time1;
-  double timebase;
-  int comoving;
-  double logTimeBegin, logTimeMax;
-  const double *drift, *gravkick, *hydrokick;  // DRIFT_TABLE_LENGTH entries each (device)
-  double minhsml;
-  int wrap;
-  double boxsize;
-};
-
-#define DRIFT_TABLE_LENGTH 1000  // allvars.h:136
-
-// driftfac.c:123-163 (and the identical :166-205, :208-247 for the kick tables)
-__device__ __forceinline__ double d_table_factor(const double *__restrict__ tab, int time0,
-                                                 int time1, const DriftK &k)
-{
-  double a1 = k.logTimeBegin + time0 * k.timebase;
-  double a2 = k.logTimeBegin + time1 * k.timebase;
-  double u1 = (a1 - k.logTimeBegin) / (k.logTimeMax - k.logTimeBegin) * DRIFT_TABLE_LENGTH;
-  int i1 = (int) u1;
-  if(i1 >= DRIFT_TABLE_LENGTH)
-    i1 = DRIFT_TABLE_LENGTH - 1;
-  double df1 = (i1 <= 1) ? u1 * tab[0] : tab[i1 - 1] + (tab[i1] - tab[i1 - 1]) * (u1 - i1);
-  double u2 = (a2 - k.logTimeBegin) / (k.logTimeMax - k.logTimeBegin) * DRIFT_TABLE_LENGTH;
-  int i2 = (int) u2;
-  if(i2 >= DRIFT_TABLE_LENGTH)
-    i2 = DRIFT_TABLE_LENGTH - 1;
-  double df2 = (i2 <= 1) ? u2 * tab[0] : tab[i2 - 1] + (tab[i2] - tab[i2 - 1]) * (u2 - i2);
-  return df2 - df1;
-}
+#include "ghip_timefac.h"
 
 __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
                         const double *__restrict__ vel, const int *__restrict__ type,

@@ -100,7 +100,8 @@ struct ghip_ctx
   // counters (device): 8 x u64
   DevBuf counters;
   ghip_stats stats;
-  hipEvent_t ev[12];
+  hipEvent_t ev[16];
+  int timestep_endrun = 0;   // endrun code of the last ghip_advance_timesteps failure
   bool ev_ready = false;
 };
 

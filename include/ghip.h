@@ -38,6 +38,8 @@ typedef struct ghip_ctx ghip_ctx;
 #define GHIP_ENOMEM (-90003)     /* device or host allocation failed */
 #define GHIP_ENOCONV (-90004)    /* density h-iteration did not converge (reference: endrun(1155)) */
 #define GHIP_ENODEVICE (-90005)  /* no usable gfx950 device */
+#define GHIP_ETIMESTEP (-90006)  /* timestep criterion failed (reference: endrun(888|818|112313));
+                                  * the code is returned by ghip_timestep_endrun_code */
 
 /* particle fields held on the device in the host's particle order.  3-vectors are [n][3]
  * doubles on the host side; ints are 32-bit. */
@@ -133,6 +135,25 @@ typedef struct
   double BoxSize;
 } ghip_drift_params;
 
+/* "next" row N1: timestep criterion + kick for the active particles
+ * (advance_and_find_timesteps timestep.c:29-362, get_timestep :607-1123 with
+ * TypeOfTimestepCriterion 0, do_the_kick :364-605; minimal flag set) */
+typedef struct
+{
+  int Ti_Current;            /* All.Ti_Current */
+  double Timebase_interval;
+  int ComovingIntegrationOn;
+  double Time;               /* All.Time */
+  double hubble_a;           /* hubble_function(All.Time) (timestep.c:56); ignored when not comoving */
+  double ErrTolIntAccuracy, CourantFac, MaxSizeTimestep, MinSizeTimestep;
+  double dt_displacement;    /* find_dt_displacement_constraint (timestep.c:1125) */
+  double SofteningTable[6];  /* All.SofteningTable (set_softenings, gravtree.c:839) */
+  double MinEgySpec;
+  unsigned int TimeBinActive; /* bit b set <=> TimeBinActive[b] (timestep.c:163) */
+  double logTimeBegin, logTimeMax;                /* driftfac.c:20 */
+  const double *GravKickTable, *HydroKickTable;   /* host, 1000 entries each; comoving only */
+} ghip_kick_params;
+
 /* work counters of the last phase, counted exactly as the reference counts them
  * (SURVEY.md 8d): used for roofline.achieved */
 typedef struct
@@ -150,6 +171,7 @@ typedef struct
   float ms_tree, ms_grav, ms_ewald, ms_dens, ms_hmax, ms_hydro;
   /* walk efficiency: elements visited summed over wavefronts (64 targets share each visit) */
   long long grav_wave_steps, ewald_wave_steps;
+  float ms_kick;                 /* k_advance_timesteps of the last ghip_advance_timesteps */
 } ghip_stats;
 
 /* ---- lifetime ---- */
@@ -191,6 +213,22 @@ int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_all, int nra
 /* ---- pre-condition of the path: drift the resident particles (replaces the lazy
  * drift_particle() calls inside the walks, forcetree.c:1911, ngb.c:57) ---- */
 int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p);
+
+/* ---- "next" row N1: timestep + kick on the resident fields.  Works on the active list of
+ * ghip_set_active.  In/out: VEL, VELPRED, ENTROPY, DTENTROPY, TIMEBIN, TI_BEGSTEP; in: GRAVACCEL
+ * (final, xG), HYDROACCEL, HSML, MAXSIGNALVEL, DENSITY, TYPE.  TimeBinCount/TimeBinCountSph
+ * (32 entries each, may be NULL) receive the recounted bin populations (allvars.h:337-338).
+ * Returns GHIP_ETIMESTEP where the reference calls endrun(); ghip_timestep_endrun_code gives the
+ * reference's code (888, 818, 112313). ---- */
+int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p, long long *TimeBinCount,
+                           long long *TimeBinCountSph);
+int ghip_timestep_endrun_code(const ghip_ctx *ctx);
+/* per-type sums of find_dt_displacement_constraint (timestep.c:1140-1156): sum of |v|^2, smallest
+ * positive mass (1e30 if none), particle count -- 6 entries each */
+int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_mass[6], long long count[6]);
+/* pack the kick's results (Vel, TimeBin, Ti_begstep; VelPred, Entropy, DtEntropy) into the device
+ * image of the records and copy the blocks to the host */
+int ghip_download_aos_kick(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay);
 
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],

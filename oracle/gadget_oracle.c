@@ -1663,3 +1663,241 @@ int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
     }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * "Next" row N1: timestep criterion + kick (timestep.c).  Live code of the minimal periodic flag
+ * set: no PMGRID, BLACK_HOLES, DUST, MAGNETIC, CONDUCTION, ... ; DoDynamicUpdate (node kicks,
+ * forcetree.c:1474-1651) is not part of it -- the device rebuilds its tree every step.
+ * ------------------------------------------------------------------------------------------- */
+#define ORC_TIMEBINS 29              /* allvars.h:39 */
+#define ORC_TIMEBASE (1 << ORC_TIMEBINS) /* allvars.h:41 */
+#define ORC_GAMMA (7.0 / 5.0)        /* allvars.h:64 (this fork) */
+#define ORC_GAMMA_MINUS1 (ORC_GAMMA - 1)
+
+/* find_dt_displacement_constraint, timestep.c:1125-1224: the per-type sums (the reference adds
+ * them up serially per task, then MPI_Allreduce) */
+void orc_velocity_moments(int n, const double *vel, const double *mass, const int *type,
+                          double v2[6], double minmass[6], long long count[6])
+{
+  for(int t = 0; t < 6; t++)
+    {
+      v2[t] = 0;
+      minmass[t] = 1.0e30;
+      count[t] = 0;
+    }
+  for(int i = 0; i < n; i++)
+    {
+      int t = type[i];
+      v2[t] += vel[3 * i] * vel[3 * i] + vel[3 * i + 1] * vel[3 * i + 1] + vel[3 * i + 2] * vel[3 * i + 2];
+      if(mass[i] > 0 && minmass[t] > mass[i])
+        minmass[t] = mass[i];
+      count[t]++;
+    }
+}
+
+/* the rest of find_dt_displacement_constraint: dt_displacement from the moments */
+double orc_dt_displacement(const double v2[6], const double minmass[6], const long long count[6],
+                           int comoving, double hfac, double MaxSizeTimestep,
+                           double MaxRMSDisplacementFac, double Omega0, double OmegaBaryon,
+                           double Hubble, double G, int StarformationOn)
+{
+  double dtd = MaxSizeTimestep;
+  if(!comoving)
+    return dtd;
+  for(int t = 0; t < 6; t++)
+    if(count[t] > 0)
+      {
+        double dmean;
+        if(t == 0 || (t == 4 && StarformationOn))
+          dmean = pow(minmass[t] / (OmegaBaryon * 3 * Hubble * Hubble / (8 * M_PI * G)), 1.0 / 3);
+        else
+          dmean = pow(minmass[t] / ((Omega0 - OmegaBaryon) * 3 * Hubble * Hubble / (8 * M_PI * G)),
+                      1.0 / 3);
+        double dt = MaxRMSDisplacementFac * hfac * dmean / sqrt(v2[t] / count[t]);
+        if(dt < dtd)
+          dtd = dt;
+      }
+  return dtd;
+}
+
+/* get_timestep_bin, timestep.c:1226-1246; -1 flags the endrun(112313) case */
+static int timestep_bin(int ti_step)
+{
+  int bin = -1;
+  if(ti_step == 0)
+    return 0;
+  if(ti_step == 1)
+    return -1;
+  while(ti_step)
+    {
+      bin++;
+      ti_step >>= 1;
+    }
+  return bin;
+}
+
+/* advance_and_find_timesteps (timestep.c:29-362) with get_timestep (:607-1123, flag == 0,
+ * TypeOfTimestepCriterion 0) and do_the_kick (:364-605) for the active particles.  Arrays:
+ * vel/gravaccel [n][3]; gas arrays [ngas](,3).  bincount/bincount_sph: TimeBinCount[] /
+ * TimeBinCountSph[] after the update, recounted over all particles.
+ * Returns 0 or the reference's endrun code (888, 818, 112313). */
+int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive, const int *active,
+                          const int *type, double *vel, const double *gravaccel,
+                          const double *hydroaccel, double *velpred, double *entropy,
+                          double *dtentropy, const double *density, const double *pressure,
+                          const double *hsml, const double *maxsignalvel, int *timebin,
+                          int *ti_begstep, long long bincount[32], long long bincount_sph[32])
+{
+  double fac1, fac2, fac3, hubble_a, atime, a3inv;
+  int err = 0;
+  if(p->ComovingIntegrationOn)
+    {
+      /* timestep.c:52-60 */
+      fac1 = 1 / (p->Time * p->Time);
+      fac2 = 1 / pow(p->Time, 3 * ORC_GAMMA - 2);
+      fac3 = pow(p->Time, 3 * (1 - ORC_GAMMA) / 2.0);
+      hubble_a = p->hubble_a;
+      a3inv = 1 / (p->Time * p->Time * p->Time);
+      atime = p->Time;
+    }
+  else
+    fac1 = fac2 = fac3 = hubble_a = a3inv = atime = 1;
+
+  for(int a = 0; a < (active ? nactive : n); a++)
+    {
+      int i = active ? active[a] : a;
+      /* ---- get_timestep ---- */
+      double ax = fac1 * gravaccel[3 * i], ay = fac1 * gravaccel[3 * i + 1],
+             az = fac1 * gravaccel[3 * i + 2];
+      if(type[i] == 0)
+        {
+          ax += fac2 * hydroaccel[3 * i];
+          ay += fac2 * hydroaccel[3 * i + 1];
+          az += fac2 * hydroaccel[3 * i + 2];
+        }
+      double ac = sqrt(ax * ax + ay * ay + az * az);
+      if(ac == 0)
+        ac = 1.0e-30;
+      double dt = sqrt(2 * p->ErrTolIntAccuracy * atime * p->SofteningTable[type[i]] / ac);
+      if(type[i] == 0)
+        {
+          double dt_courant;
+          if(p->ComovingIntegrationOn)
+            dt_courant = 2 * p->CourantFac * p->Time * hsml[i] / (fac3 * maxsignalvel[i]);
+          else
+            dt_courant = 2 * p->CourantFac * hsml[i] / maxsignalvel[i];
+          if(dt_courant < dt)
+            dt = dt_courant;
+        }
+      dt *= hubble_a;
+      if(dt >= p->MaxSizeTimestep)
+        dt = p->MaxSizeTimestep;
+      if(dt >= p->dt_displacement)
+        dt = p->dt_displacement;
+      if(dt < p->MinSizeTimestep)
+        {
+          err = err > 888 ? err : 888; /* timestep.c:1082 */
+          continue;
+        }
+      int ti_step = (int) (dt / p->Timebase_interval);
+      if(!(ti_step > 0 && ti_step < ORC_TIMEBASE))
+        {
+          err = err > 818 ? err : 818; /* timestep.c:1119 */
+          continue;
+        }
+      /* ---- advance_and_find_timesteps loop body, timestep.c:146-260 ---- */
+      int ti_min = ORC_TIMEBASE;
+      while(ti_min > ti_step)
+        ti_min >>= 1;
+      ti_step = ti_min;
+      int bin = timestep_bin(ti_step);
+      if(bin < 0)
+        {
+          err = err > 112313 ? err : 112313;
+          continue;
+        }
+      int binold = timebin[i];
+      if(bin > binold)
+        if(((p->TimeBinActive >> bin) & 1u) == 0)
+          {
+            bin = binold;
+            ti_step = bin ? (1 << bin) : 0;
+          }
+      if(p->Ti_Current >= ORC_TIMEBASE)
+        {
+          ti_step = 0;
+          bin = 0;
+        }
+      if((ORC_TIMEBASE - p->Ti_Current) < ti_step)
+        {
+          err = err > 888 ? err : 888; /* timestep.c:171 */
+          continue;
+        }
+      timebin[i] = bin;
+      int ti_step_old = binold ? (1 << binold) : 0;
+      int tstart = ti_begstep[i] + ti_step_old / 2;
+      int tend = ti_begstep[i] + ti_step_old + ti_step / 2;
+      ti_begstep[i] += ti_step_old;
+      int tcurrent = ti_begstep[i];
+      /* ---- do_the_kick ---- */
+      double dt_entr, dt_gravkick, dt_hydrokick, dt_gravkick2, dt_hydrokick2;
+      if(p->ComovingIntegrationOn)
+        {
+          dt_entr = (tend - tstart) * p->Timebase_interval;
+          dt_gravkick = table_factor(p->tables + 1000, tstart, tend, p->Timebase_interval,
+                                     p->logTimeBegin, p->logTimeMax);
+          dt_hydrokick = table_factor(p->tables + 2000, tstart, tend, p->Timebase_interval,
+                                      p->logTimeBegin, p->logTimeMax);
+          dt_gravkick2 = table_factor(p->tables + 1000, tcurrent, tend, p->Timebase_interval,
+                                      p->logTimeBegin, p->logTimeMax);
+          dt_hydrokick2 = table_factor(p->tables + 2000, tcurrent, tend, p->Timebase_interval,
+                                       p->logTimeBegin, p->logTimeMax);
+        }
+      else
+        {
+          dt_entr = dt_gravkick = dt_hydrokick = (tend - tstart) * p->Timebase_interval;
+          dt_gravkick2 = dt_hydrokick2 = (tend - tcurrent) * p->Timebase_interval;
+        }
+      for(int j = 0; j < 3; j++)
+        vel[3 * i + j] += gravaccel[3 * i + j] * dt_gravkick;
+      if(type[i] == 0)
+        {
+          for(int j = 0; j < 3; j++)
+            {
+              vel[3 * i + j] += hydroaccel[3 * i + j] * dt_hydrokick;
+              velpred[3 * i + j] = vel[3 * i + j] - dt_gravkick2 * gravaccel[3 * i + j] -
+                                   dt_hydrokick2 * hydroaccel[3 * i + j];
+            }
+          /* timestep.c:553-557 (DO_NOT_PROTECT off) */
+          if(dtentropy[i] * dt_entr > -0.5 * entropy[i])
+            entropy[i] += dtentropy[i] * dt_entr;
+          else
+            entropy[i] *= 0.5;
+          if(p->MinEgySpec)
+            {
+              double minentropy =
+                p->MinEgySpec * ORC_GAMMA_MINUS1 / pow(density[i] * a3inv, ORC_GAMMA_MINUS1);
+              if(entropy[i] < minentropy)
+                {
+                  entropy[i] = minentropy;
+                  dtentropy[i] = 0;
+                }
+            }
+          /* timestep.c:590-593 */
+          dt_entr = (timebin[i] ? (1 << timebin[i]) : 0) / 2 * p->Timebase_interval;
+          if(entropy[i] + dtentropy[i] * dt_entr < 0.5 * entropy[i])
+            dtentropy[i] = -0.5 * entropy[i] / dt_entr;
+        }
+    }
+  (void) pressure;
+  for(int b = 0; b < 32; b++)
+    bincount[b] = bincount_sph[b] = 0;
+  for(int i = 0; i < n; i++)
+    {
+      bincount[timebin[i]]++;
+      if(type[i] == 0)
+        bincount_sph[timebin[i]]++;
+    }
+  (void) ngas;
+  return err;
+}

@@ -147,6 +147,35 @@ int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
               const double *hydroaccel, double *density, double *hsml, const double *divvel,
               const double *entropy, const double *dtentropy, double *pressure);
 
+/* ---- "next" row N1: timestep criterion + kick (timestep.c:29-605, 607-1123, 1125-1246),
+ * minimal flag set; tables as in orc_drift (NULL when not comoving) ---- */
+typedef struct
+{
+  int Ti_Current;
+  double Timebase_interval;
+  int ComovingIntegrationOn;
+  double Time, hubble_a;
+  double ErrTolIntAccuracy, CourantFac, MaxSizeTimestep, MinSizeTimestep, dt_displacement;
+  double SofteningTable[6];
+  double MinEgySpec;
+  unsigned int TimeBinActive; /* bit b: TimeBinActive[b] */
+  const double *tables;       /* [3][1000] drift, gravkick, hydrokick */
+  double logTimeBegin, logTimeMax;
+} orc_kick_params;
+
+void orc_velocity_moments(int n, const double *vel, const double *mass, const int *type,
+                          double v2[6], double minmass[6], long long count[6]);
+double orc_dt_displacement(const double v2[6], const double minmass[6], const long long count[6],
+                           int comoving, double hfac, double MaxSizeTimestep,
+                           double MaxRMSDisplacementFac, double Omega0, double OmegaBaryon,
+                           double Hubble, double G, int StarformationOn);
+int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive, const int *active,
+                          const int *type, double *vel, const double *gravaccel,
+                          const double *hydroaccel, double *velpred, double *entropy,
+                          double *dtentropy, const double *density, const double *pressure,
+                          const double *hsml, const double *maxsignalvel, int *timebin,
+                          int *ti_begstep, long long bincount[32], long long bincount_sph[32]);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int nthreads);
 

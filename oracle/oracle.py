@@ -321,6 +321,69 @@ def drift(time1, timebase, pos, vel, ptype, ti_current, timebin, ti_begstep, gra
     return out
 
 
+class KickParams(C.Structure):
+    """orc_kick_params (timestep.c parameters of the minimal flag set)"""
+    _fields_ = [("Ti_Current", C.c_int), ("Timebase_interval", C.c_double),
+                ("ComovingIntegrationOn", C.c_int), ("Time", C.c_double), ("hubble_a", C.c_double),
+                ("ErrTolIntAccuracy", C.c_double), ("CourantFac", C.c_double),
+                ("MaxSizeTimestep", C.c_double), ("MinSizeTimestep", C.c_double),
+                ("dt_displacement", C.c_double), ("SofteningTable", C.c_double * 6),
+                ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint), ("tables", C.c_void_p),
+                ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double)]
+
+
+def velocity_moments(vel, mass, ptype):
+    """find_dt_displacement_constraint's per-type sums (timestep.c:1140-1156)."""
+    L = lib()
+    v2, mm = np.zeros(6), np.zeros(6)
+    cnt = np.zeros(6, np.int64)
+    L.orc_velocity_moments.argtypes = [C.c_int] + [C.c_void_p] * 6
+    L.orc_velocity_moments(len(mass), _p(_f64(vel)), _p(_f64(mass)), _p(_i32(ptype)), _p(v2),
+                           _p(mm), _p(cnt))
+    return v2, mm, cnt
+
+
+def dt_displacement(v2, minmass, count, comoving, hfac, max_size_timestep, max_rms_fac, omega0,
+                    omega_baryon, hubble, G, starformation=0):
+    L = lib()
+    L.orc_dt_displacement.restype = C.c_double
+    L.orc_dt_displacement.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
+        [C.c_double] * 7 + [C.c_int]
+    return L.orc_dt_displacement(_p(_f64(v2)), _p(_f64(minmass)),
+                                 _p(np.ascontiguousarray(count, dtype=np.int64)), int(comoving),
+                                 float(hfac), float(max_size_timestep), float(max_rms_fac),
+                                 float(omega0), float(omega_baryon), float(hubble), float(G),
+                                 int(starformation))
+
+
+def advance_timesteps(params, ptype, vel, gravaccel, hydroaccel, velpred, entropy, dtentropy,
+                      density, pressure, hsml, maxsignalvel, timebin, ti_begstep, active=None,
+                      tables=None):
+    """advance_and_find_timesteps + get_timestep + do_the_kick on copies; returns the updated
+    arrays, the bin counts and rc (0 or the reference's endrun code)."""
+    n, ngas = len(ptype), len(entropy)
+    out = dict(vel=_f64(vel).copy(), velpred=_f64(velpred).copy(), entropy=_f64(entropy).copy(),
+               dtentropy=_f64(dtentropy).copy(), timebin=_i32(timebin).copy(),
+               ti_begstep=_i32(ti_begstep).copy())
+    tabs = None
+    if tables is not None:
+        tabs = _f64(np.concatenate([np.ravel(t) for t in tables]))
+        params.tables = tabs.ctypes.data
+    cnt = np.zeros(32, np.int64)
+    sph = np.zeros(32, np.int64)
+    act = None if active is None else _i32(active)
+    L = lib()
+    L.orc_advance_timesteps.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 16
+    rc = L.orc_advance_timesteps(n, ngas, C.addressof(params), 0 if act is None else len(act),
+                                 _p(act), _p(_i32(ptype)), _p(out["vel"]), _p(_f64(gravaccel)),
+                                 _p(_f64(hydroaccel)), _p(out["velpred"]), _p(out["entropy"]),
+                                 _p(out["dtentropy"]), _p(_f64(density)), _p(_f64(pressure)),
+                                 _p(_f64(hsml)), _p(_f64(maxsignalvel)), _p(out["timebin"]),
+                                 _p(out["ti_begstep"]), _p(cnt), _p(sph))
+    out.update(rc=rc, bincount=cnt, bincount_sph=sph)
+    return out
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 

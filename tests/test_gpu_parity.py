@@ -649,6 +649,137 @@ def test_drift_parity(comoving):
 
 
 # ------------------------------------------------------------------------------------------------
+# "next" row N1: timestep criterion + kick (timestep.c)
+# ------------------------------------------------------------------------------------------------
+def _kick_case(pr, comoving, seed=31):
+    rng = np.random.default_rng(seed)
+    n, ng = pr.n, pr.ngas
+    st = dict(
+        grav=rng.standard_normal((n, 3)) * 10 ** rng.uniform(-1, 1.5, (n, 1)),
+        hyd=rng.standard_normal((ng, 3)) * 3.0,
+        vsig=0.5 + 2 * rng.random(ng),
+        dens=1.0 + rng.random(ng),
+        pres=rng.random(ng),
+        hs=pr.hsml0[:ng] * (0.5 + rng.random(ng)),
+        entropy=0.05 * (1 + rng.random(ng)),
+        # a few strongly cooling particles exercise the factor-0.5 entropy protection
+        dtentropy=np.where(rng.random(ng) < 0.1, -50.0, 0.3) * rng.random(ng),
+        timebin=rng.integers(19, 25, n).astype(np.int32),
+    )
+    st["ti_begstep"] = (rng.integers(0, 4, n) << 25).astype(np.int32)
+    par = dict(Ti_Current=1 << 27, Timebase_interval=1.0 / (1 << 29), ComovingIntegrationOn=0,
+               Time=1.0, hubble_a=1.0, ErrTolIntAccuracy=0.025, CourantFac=0.15,
+               MaxSizeTimestep=0.02, MinSizeTimestep=1e-9, dt_displacement=0.015,
+               MinEgySpec=0.0, TimeBinActive=0b1010110101 << 16, logTimeBegin=0.0,
+               logTimeMax=0.0)
+    tabs = None
+    if comoving:
+        t = np.linspace(0.01, 1.0, 1000)
+        tabs = [np.cumsum(t ** 1.5) * 1e-3, np.cumsum(t ** 0.5) * 1e-3, np.cumsum(t ** 0.2) * 1e-3]
+        par.update(ComovingIntegrationOn=1, Time=0.37, hubble_a=1.9, MinEgySpec=0.02,
+                   logTimeBegin=np.log(0.02), logTimeMax=np.log(1.0))
+        par["Timebase_interval"] = (par["logTimeMax"] - par["logTimeBegin"]) / (1 << 29)
+    return st, par, tabs
+
+
+def _fill(P, par, soft):
+    for k, v in par.items():
+        setattr(P, k, v)
+    for t in range(6):
+        P.SofteningTable[t] = soft[t]
+    return P
+
+
+@pytest.mark.parametrize("comoving", [False, True])
+@pytest.mark.parametrize("subset", [False, True])
+def test_timestep_and_kick_parity(comoving, subset):
+    """advance_and_find_timesteps / get_timestep / do_the_kick on the resident fields against the
+    CPU restatement: TimeBin, Ti_begstep and the bin counts exactly, the kicked quantities to
+    bit (no fma contraction in that file)."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    st, par, tabs = _kick_case(pr, comoving)
+    soft = pr.force_soft / 2.8
+    fp = pr.device()
+    hfull = pr.hsml0.copy()
+    hfull[:ng] = st["hs"]
+    for fid, arr in ((B.F_GRAVACCEL, st["grav"]), (B.F_HYDROACCEL, st["hyd"]),
+                     (B.F_MAXSIGNALVEL, st["vsig"]), (B.F_DENSITY, st["dens"]),
+                     (B.F_PRESSURE, st["pres"]), (B.F_HSML, hfull), (B.F_ENTROPY, st["entropy"]),
+                     (B.F_DTENTROPY, st["dtentropy"]), (B.F_TIMEBIN, st["timebin"]),
+                     (B.F_TI_BEGSTEP, st["ti_begstep"])):
+        fp.set_field(fid, arr)
+    active = None
+    if subset:
+        active = np.sort(np.random.default_rng(5).choice(n, n // 3, replace=False)).astype(np.int32)
+        fp.set_active(active)
+    cnt, sph = fp.advance_timesteps(_fill(B.KickParams(), par, soft),
+                                    kick_tables=None if tabs is None else tabs[1:])
+    want = O.advance_timesteps(_fill(O.KickParams(), par, soft), pr.ic["type"], pr.ic["vel"],
+                               st["grav"], st["hyd"], pr.velpred, st["entropy"], st["dtentropy"],
+                               st["dens"], st["pres"], st["hs"], st["vsig"], st["timebin"],
+                               st["ti_begstep"], active=active, tables=tabs)
+    assert want["rc"] == 0
+    assert np.array_equal(fp.get_field(B.F_TIMEBIN), want["timebin"])
+    assert np.array_equal(fp.get_field(B.F_TI_BEGSTEP), want["ti_begstep"])
+    assert np.array_equal(cnt, want["bincount"]) and np.array_equal(sph, want["bincount_sph"])
+    assert cnt.sum() == n and sph.sum() == ng
+    assert len(np.unique(want["timebin"])) > 2          # the case spans several bins
+    # the kick file is compiled without fma contraction: bit-identical to the CPU arithmetic,
+    # except where pow() enters (MinEgySpec floor, comoving case only)
+    assert np.array_equal(fp.get_field(B.F_VEL), want["vel"])
+    assert np.array_equal(fp.get_field(B.F_VELPRED), want["velpred"])
+    if comoving:
+        assert relerr(fp.get_field(B.F_ENTROPY), want["entropy"]) < 1e-14
+        assert np.abs(fp.get_field(B.F_DTENTROPY) - want["dtentropy"]).max() <= \
+            1e-14 * np.abs(want["dtentropy"]).max()
+    else:
+        assert np.array_equal(fp.get_field(B.F_ENTROPY), want["entropy"])
+        assert np.array_equal(fp.get_field(B.F_DTENTROPY), want["dtentropy"])
+    if subset:
+        # inactive particles are untouched
+        rest = np.setdiff1d(np.arange(n), active)
+        assert np.array_equal(fp.get_field(B.F_VEL)[rest], pr.ic["vel"][rest])
+        assert np.array_equal(fp.get_field(B.F_TIMEBIN)[rest], st["timebin"][rest])
+    assert fp.stats()["ms_kick"] > 0
+
+
+def test_timestep_failure_reports_the_reference_endrun_code():
+    B = bindings()
+    pr = Problem(ng=6, gas=True, periodic=1)
+    st, par, _ = _kick_case(pr, False)
+    fp = pr.device()
+    for fid, arr in ((B.F_GRAVACCEL, st["grav"]), (B.F_HYDROACCEL, st["hyd"]),
+                     (B.F_MAXSIGNALVEL, st["vsig"]), (B.F_TIMEBIN, st["timebin"]),
+                     (B.F_TI_BEGSTEP, st["ti_begstep"])):
+        fp.set_field(fid, arr)
+    par["MinSizeTimestep"] = 1.0            # every step is "below the limit": endrun(888)
+    with pytest.raises(B.GhipError) as ei:
+        fp.advance_timesteps(_fill(B.KickParams(), par, pr.force_soft / 2.8))
+    assert ei.value.endrun == 888
+    par["MinSizeTimestep"] = 0.0
+    par["Timebase_interval"] = 1.0          # dt / Timebase_interval truncates to 0: endrun(818)
+    with pytest.raises(B.GhipError) as ei:
+        fp.advance_timesteps(_fill(B.KickParams(), par, pr.force_soft / 2.8))
+    assert ei.value.endrun == 818
+
+
+def test_velocity_moments_match_the_serial_sums():
+    """find_dt_displacement_constraint's per-type <v^2>, min mass and counts (timestep.c:1140)."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    fp = pr.device()
+    v2, mm, cnt = fp.velocity_moments()
+    ov2, omm, ocnt = O.velocity_moments(pr.ic["vel"], pr.ic["mass"], pr.ic["type"])
+    assert np.array_equal(cnt, ocnt) and np.array_equal(mm, omm)
+    assert np.allclose(v2, ov2, rtol=1e-13, atol=0)
+    d = O.dt_displacement(v2, mm, cnt, 1, 0.37 ** 2 * 1.9, 0.05, 0.25, 0.3, 0.04, 0.1, 43007.1)
+    od = O.dt_displacement(ov2, omm, ocnt, 1, 0.37 ** 2 * 1.9, 0.05, 0.25, 0.3, 0.04, 0.1, 43007.1)
+    assert abs(d - od) <= 1e-13 * od
+
+
+# ------------------------------------------------------------------------------------------------
 # BASELINE configs at full size: size-independent properties (the oracle would take too long
 # for everything, so it checks a sample and the domain's invariants check the rest)
 # ------------------------------------------------------------------------------------------------

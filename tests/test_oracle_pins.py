@@ -264,3 +264,72 @@ def test_hydro_conserves_momentum_and_vanishes_for_uniform_static_gas():
     P_over_rho_h = (od["pressure"][0] / od["density"][0]) / od["hsml"][0]
     assert np.abs(oh["hydroaccel"][:pr2.ngas]).max() < 1e-9 * P_over_rho_h
     assert np.abs(oh["dtentropy"][:pr2.ngas]).max() == 0
+
+
+def test_timestep_and_kick_restatement_against_hand_evaluation():
+    """orc_advance_timesteps (timestep.c:29-605, minimal flag set) pinned by evaluating the same
+    formulas in plain Python for a handful of particles: power-of-two step, the bin
+    synchronisation rule, leapfrog kick mid-points and the entropy protection."""
+    TIMEBASE = 1 << 29
+    tb = 1.0 / TIMEBASE
+    soft = np.array([0.01, 0.02, 0.02, 0.02, 0.02, 0.02])
+    ptype = np.array([0, 1, 1, 0], np.int32)
+    ng = 2                                    # gas particles are 0 and ... only index < ngas
+    ptype = np.array([0, 0, 1, 1], np.int32)
+    vel = np.arange(12.0).reshape(4, 3) * 0.1
+    grav = np.array([[1.0, 0, 0], [0, 2.0, 0], [0, 0, 4.0], [3.0, 0, 4.0]])
+    hyd = np.array([[0.5, 0, 0], [0, 0, -1.0]])
+    vsig = np.array([1.0, 50.0])              # second gas particle is Courant limited
+    hs = np.array([0.1, 0.1])
+    entropy = np.array([1.0, 1.0])
+    dtentropy = np.array([0.25, -1.0e9])      # second: entropy may only halve
+    timebin = np.array([20, 20, 20, 22], np.int32)
+    tbeg = np.array([0, 1 << 20, 0, 0], np.int32)
+    P = O.KickParams()
+    P.Ti_Current, P.Timebase_interval, P.ComovingIntegrationOn = 1 << 21, tb, 0
+    P.Time, P.hubble_a = 1.0, 1.0
+    P.ErrTolIntAccuracy, P.CourantFac = 0.025, 0.15
+    P.MaxSizeTimestep, P.MinSizeTimestep, P.dt_displacement = 0.05, 1e-12, 0.05
+    for t in range(6):
+        P.SofteningTable[t] = soft[t]
+    P.MinEgySpec = 0.0
+    P.TimeBinActive = (1 << 20) | (1 << 21)   # bins 20, 21 synchronised; 22+ not
+    out = O.advance_timesteps(P, ptype, vel, grav, hyd, vel[:ng].copy(), entropy, dtentropy,
+                              np.ones(ng), np.ones(ng), hs, vsig, timebin, tbeg)
+    assert out["rc"] == 0
+    for i in range(4):
+        a = grav[i] + (hyd[i] if ptype[i] == 0 else 0)
+        ac = np.sqrt((a * a).sum())
+        dt = np.sqrt(2 * 0.025 * soft[ptype[i]] / ac)
+        if ptype[i] == 0:
+            dt = min(dt, 2 * 0.15 * hs[i] / vsig[i])
+        dt = min(dt, 0.05)
+        ti = int(dt / tb)
+        step = TIMEBASE
+        while step > ti:
+            step >>= 1
+        b = step.bit_length() - 1
+        if b > timebin[i] and not (P.TimeBinActive >> b) & 1:
+            b = int(timebin[i])
+            step = 1 << b
+        assert out["timebin"][i] == b
+        old = 1 << int(timebin[i])
+        assert out["ti_begstep"][i] == tbeg[i] + old
+        tstart, tend = tbeg[i] + old // 2, tbeg[i] + old + step // 2
+        dtk = (tend - tstart) * tb
+        v = vel[i] + grav[i] * dtk
+        if ptype[i] == 0:
+            v = v + hyd[i] * dtk
+            dt2 = (tend - (tbeg[i] + old)) * tb
+            assert np.allclose(out["velpred"][i], v - dt2 * grav[i] - dt2 * hyd[i], rtol=1e-15)
+        assert np.allclose(out["vel"][i], v, rtol=1e-15)
+    # particle 3 wanted a larger step than its bin 22 but 23.. are not active -> unchanged bin
+    assert out["entropy"][0] > 1.0 and out["entropy"][1] == 0.5
+    # overcooling guard (timestep.c:590-593): A + dA*dt_half >= A/2
+    half = (1 << int(out["timebin"][1])) // 2 * tb
+    assert out["entropy"][1] + out["dtentropy"][1] * half >= 0.5 * out["entropy"][1] * (1 - 1e-15)
+    assert out["bincount"].sum() == 4 and out["bincount_sph"].sum() == 2
+    # failure paths carry the reference's endrun codes
+    P.MinSizeTimestep = 1.0
+    assert O.advance_timesteps(P, ptype, vel, grav, hyd, vel[:ng].copy(), entropy, dtentropy,
+                               np.ones(ng), np.ones(ng), hs, vsig, timebin, tbeg)["rc"] == 888
