@@ -858,3 +858,54 @@ def test_config_c2_64cubed_full_step_properties():
                    pr.ti_begstep, pr.hsml0)
     assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
     assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
+
+
+def test_config_c3_128cubed_shortrange_tree_and_sph_sampled():
+    """c3 (128^3 DM + 128^3 gas, TreePM): the GPU part of the configuration -- the short-range tree
+    walk (PMGRID = 128; the long-range PM force stays on the host FFT and is out of scope) plus SPH
+    density and hydro on 4.2 million particles, against the oracle on a sample of targets, and the
+    size-independent invariants over all of them."""
+    B = bindings()
+    pr = Problem(ng=128, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    assert n == 2 * 128 ** 3
+    asmth = 1.25 * pr.box / 128          # ASMTH * BoxSize / PMGRID  (pm_periodic.c:83-84)
+    rcut = 4.5 * asmth
+    fp = pr.device()
+    pr.device_tree(fp)
+    old = np.full(n, 2.0)
+    fp.set_field(B.F_OLDACC, old)
+    fp.gravity(pr.g_grav(0.0, rcut, asmth), B.WALK_SHORTRANGE)
+    acc = fp.get_field(B.F_GRAVACCEL)
+    cost = fp.get_field(B.F_GRAVCOST)
+    st = fp.stats()
+    assert int(cost.astype(np.int64).sum()) == st["grav_interactions"]
+    assert st["tree_nodes"] > 0.3 * n and np.isfinite(acc).all()
+    rng = np.random.default_rng(11)
+    sample = np.sort(rng.choice(n, 1024, replace=False)).astype(np.int32)
+    T = pr.oracle_tree()
+    assert T.numnodes == st["tree_nodes"]
+    oacc, ocost = T.gravity(pr.o_grav(0.0, "shortrange", rcut, asmth), sample, old,
+                            kind="shortrange")
+    assert np.array_equal(cost[sample], ocost)
+    assert relerr(acc[sample], oacc) < TOL
+    # short-range forces are pairwise antisymmetric up to the opening error
+    m = pr.ic["mass"]
+    ptot = (m[:, None] * acc).sum(axis=0)
+    assert np.abs(ptot).max() < 5e-3 * np.abs(m[:, None] * acc).sum(axis=0).max()
+    # SPH on all 2.1 million gas particles
+    fp.density(pr.g_dens())
+    fp.update_hmax()
+    fp.hydro(pr.g_hydro())
+    nn = fp.get_field(B.F_NUMNGB)
+    assert np.all(np.abs(nn - pr.des_ngb) <= pr.max_dev + 1e-9)
+    ha = fp.get_field(B.F_HYDROACCEL)
+    mg = m[:ng]
+    ph = (mg[:, None] * ha).sum(axis=0)
+    assert np.abs(ph).max() < 1e-10 * np.abs(mg[:, None] * ha).sum()
+    act = sample[sample < ng][:256]
+    od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                   pr.ti_begstep, pr.hsml0)
+    assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
+    assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
+    assert np.abs(nn[act] - od["numngb"][act]).max() < 1e-10    # kernel-weighted count (density.c:876)
