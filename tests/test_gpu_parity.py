@@ -909,3 +909,39 @@ def test_config_c3_128cubed_shortrange_tree_and_sph_sampled():
     assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
     assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
     assert np.abs(nn[act] - od["numngb"][act]).max() < 1e-10    # kernel-weighted count (density.c:876)
+
+
+def test_config_c5_size_256cubed_one_step_sampled():
+    """The particle load of c5 (256^3 DM + 256^3 gas = 33.5 million; its star-formation and
+    black-hole loops are out of scope): one full force step from the 25 GB resident state, gravity
+    checked against the oracle on a sample, SPH through the neighbour window and momentum balance.
+    Guards the 64-bit offsets of every kernel."""
+    B = bindings()
+    pr = Problem(ng=256, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    fp = pr.device()
+    pr.device_tree(fp)
+    old = np.full(n, 2.0)
+    fp.set_field(B.F_OLDACC, old)
+    fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON)
+    fp.gravity(pr.g_grav(0.0), B.WALK_EWALD)
+    acc = fp.get_field(B.F_GRAVACCEL)
+    cost = fp.get_field(B.F_GRAVCOST)
+    st = fp.stats()
+    assert int(cost.astype(np.int64).sum()) == st["grav_interactions"] + st["ewald_interactions"]
+    assert np.isfinite(acc).all()
+    fp.density(pr.g_dens())
+    fp.update_hmax()
+    fp.hydro(pr.g_hydro())
+    nn = fp.get_field(B.F_NUMNGB)
+    assert np.all(np.abs(nn - pr.des_ngb) <= pr.max_dev + 1e-9)
+    ha = fp.get_field(B.F_HYDROACCEL)
+    mg = pr.ic["mass"][:ng]
+    assert np.abs((mg[:, None] * ha).sum(axis=0)).max() < 1e-10 * np.abs(mg[:, None] * ha).sum()
+    T = pr.oracle_tree()
+    assert T.numnodes == st["tree_nodes"]
+    sample = np.sort(np.random.default_rng(3).choice(n, 512, replace=False)).astype(np.int32)
+    oacc, ocost = T.gravity(pr.o_grav(0.0), sample, old)
+    T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
+    assert np.array_equal(cost[sample], ocost)
+    assert relerr(acc[sample], oacc) < TOL
