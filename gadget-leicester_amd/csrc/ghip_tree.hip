@@ -128,19 +128,6 @@ __device__ __forceinline__ unsigned int d_peano_top(int x, int y, int z, int lev
   return k;
 }
 
-__global__ void k_peano_from_pos(int n, const double *__restrict__ x, const double *__restrict__ y,
-                                 const double *__restrict__ z, double cx, double cy, double cz,
-                                 double fac, unsigned long long *__restrict__ key,
-                                 int *__restrict__ idx)
-{
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  key[i] = d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac),
-                     (int) ((z[i] - cz) * fac));
-  idx[i] = i;
-}
-
 __global__ void k_peano_from_ints(int n, const int *__restrict__ x, const int *__restrict__ y,
                                   const int *__restrict__ z, int bits,
                                   unsigned long long *__restrict__ key)
@@ -214,13 +201,6 @@ extern "C" int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y
 // ---------------------------------------------------------------------------------------------
 // structure from sorted keys
 // ---------------------------------------------------------------------------------------------
-__global__ void k_inverse_perm(int n, const int *__restrict__ perm, int *__restrict__ iperm)
-{
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if(s < n)
-    iperm[perm[s]] = s;
-}
-
 // number of leading 3-bit digits two 63-bit keys share
 __device__ __forceinline__ int d_common_levels(unsigned long long a, unsigned long long b)
 {
@@ -419,41 +399,9 @@ __global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
   aux[e] = (GRAV && mixed) ? -amax : amax;
 }
 
-__global__ void k_set_particle_aux(int nelem, const int4 *__restrict__ lk,
-                                   const double *__restrict__ paux, double *__restrict__ aux)
-{
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
-    return;
-  int4 me = lk[e];
-  if(me.y >= 0)
-    aux[e] = paux[me.y];
-}
-
 // ---------------------------------------------------------------------------------------------
 // gathers into tree order
 // ---------------------------------------------------------------------------------------------
-__global__ void k_gather_grav(int n, const int *__restrict__ perm, const double *__restrict__ x,
-                              const double *__restrict__ y, const double *__restrict__ z,
-                              const double *__restrict__ m, const int *__restrict__ type,
-                              double s0, double s1, double s2, double s3, double s4, double s5,
-                              double *__restrict__ sx, double *__restrict__ sy,
-                              double *__restrict__ sz, double *__restrict__ sm,
-                              double *__restrict__ ssoft)
-{
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if(s >= n)
-    return;
-  int i = perm[s];
-  sx[s] = x[i];
-  sy[s] = y[i];
-  sz[s] = z[i];
-  sm[s] = m[i];
-  int t = type[i];
-  double sf = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
-  ssoft[s] = sf;
-}
-
 __global__ void k_gather_f64(int n, const int *__restrict__ perm, const double *__restrict__ src,
                              double *__restrict__ dst)
 {
@@ -505,13 +453,6 @@ int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, do
   k_gather_f64<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, perm, src, dst);
   HIPCHK(hipGetLastError());
   return GHIP_OK;
-}
-
-__global__ void k_iota(int n, int *__restrict__ a)
-{
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i < n)
-    a[i] = i;
 }
 
 __global__ void k_mark_active(int nact, const int *__restrict__ act, const int *__restrict__ iperm,

@@ -44,7 +44,7 @@ struct GravK
   double boxsize, boxhalf;
   int periodic, unequal;
   int debug_steps;     // GHIP_DEBUG_STEPS=1: GRAVCOST receives the wave's visited-element count
-  int xcd_remap;       // GHIP_WALK_XCD=0 disables the XCD-contiguous block order
+  int xcd_remap;       // GHIP_WALK_XCD=1: XCD-contiguous block order (off: measured slower)
   double rcut, rcut2, asmthfac;  // shortrange
   double fac_intp;     // ewald: 2*EN/BoxSize
 };
