@@ -111,6 +111,10 @@ __device__ __forceinline__ void d_wait_touch(v16i &A, int &s1, int &s2)
 {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(s1), "+s"(s2) : : "memory");
 }
+__device__ __forceinline__ void d_drain_touch(int &s1, int &s2)
+{
+  asm volatile("s_waitcnt lgkmcnt(0) ; drain-touches" : "+s"(s1), "+s"(s2) : : "memory");
+}
 __device__ __forceinline__ void d_wait1(v16i &A)
 {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
@@ -562,15 +566,15 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
             d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
           if(A.e >= A.s1)
             {
+              // drain the touches first: their scratch registers must not be live while a load
+              // into them is in flight across code the register allocator is free to spill in
+              d_drain_touch(t1, t2);
               A.kseg += stride;
               liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab,
                                                                ewtab, valid, W, skipA, steps);
             }
         }
-      {
-        v16i Z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        d_wait_touch(Z, t1, t2);   // nothing in flight when the scratch registers are given up
-      }
+      d_drain_touch(t1, t2);
     }
   else
     {

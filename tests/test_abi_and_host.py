@@ -160,3 +160,48 @@ def test_product_package_does_not_import_the_oracle():
                 for needle in ("import oracle", "from oracle", "libgadget_oracle", "orc_",
                                "gadget_oracle.h"):
                     assert needle not in txt, (root, f, needle)
+
+
+def test_walk_touch_registers_stay_reserved_inside_the_loop():
+    """ghip_walk.h touches the successor records with one-dword scalar loads whose destination
+    registers are written asynchronously.  That is only sound while nothing else uses those
+    registers between the touch and the next s_waitcnt, so check the generated code: in every
+    k_grav_walk instantiation that touches, from the touches to the drain before the segment switch
+    the destination registers appear in no other instruction (no use, no spill, no copy)."""
+    import subprocess
+    import tempfile
+    hipcc = pkg.hipcc_path()
+    src = os.path.join(pkg.PKG_DIR, "csrc", "ghip_gravity.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "g.s")
+        subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-S",
+                        "--cuda-device-only", "-o", out, src], check=True,
+                       stderr=subprocess.DEVNULL)
+        text = open(out).read().split("\n")
+    # kernels: from "<symbol>:" to s_endpgm
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z11k_grav_walk\S*:", l)]
+    assert len(starts) >= 12
+    checked = 0
+    for s0 in starts:
+        s1 = next(i for i in range(s0, len(text)) if "s_endpgm" in text[i])
+        body = text[s0:s1]
+        # a touch = an inline-asm s_load_dword (between #ASMSTART / #ASMEND markers)
+        touches = [i for i in range(1, len(body))
+                   if "#ASMSTART" in body[i - 1] and re.search(r"\ss_load_dword\s+s\d+,", body[i])]
+        if not touches:
+            continue
+        regs = {int(re.search(r"s_load_dword\s+s(\d+),", body[i]).group(1)) for i in touches}
+        # the window in which a touch may be in flight: from the touch to the drain that precedes
+        # the segment switch (laid out after the step body; marked in the asm text)
+        drain = next(i for i in range(touches[-1], len(body)) if "drain-touches" in body[i])
+        for i in range(touches[0], drain):
+            ins = body[i].split(";")[0]
+            if i in touches or not ins.strip():
+                continue
+            for m in re.finditer(r"\bs(\d+)\b", ins):
+                assert int(m.group(1)) not in regs, ins
+            for m in re.finditer(r"s\[(\d+):(\d+)\]", ins):
+                lo, hi = int(m.group(1)), int(m.group(2))
+                assert not any(lo <= r <= hi for r in regs), ins
+        checked += 1
+    assert checked >= 4      # the Newtonian and short-range walks, periodic or not
