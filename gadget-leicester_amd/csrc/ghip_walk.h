@@ -86,42 +86,57 @@ __device__ __forceinline__ double d_f64(const v16i &v, int i)
   return __hiloint2double(v[2 * i + 1], v[2 * i]);
 }
 
-// issue a 64-byte scalar load of record `e` (wave-uniform); the caller waits with d_wait_*
+// Scalar loads of 64-byte records (wave-uniform index).  Load and wait are ONE asm statement:
+// a scalar load writes its destination asynchronously, and between two asm statements the
+// register allocator would be free to copy or spill a destination that is still in flight.
 template <class T>
-__device__ __forceinline__ void d_issue_load(const T *__restrict__ base, int e, v16i &R)
+__device__ __forceinline__ const T *d_uniform_ptr(const T *__restrict__ base, int e)
 {
   unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
   unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
   unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
-  const T *p = reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
-  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(R) : "s"(p) : "memory");
+  return reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
 }
-// touch record `e` so that its cache line is on its way into the scalar cache: one dword into a
-// scratch SGPR, which stays reserved until d_wait_touch (the load writes it asynchronously)
+template <class T>
+__device__ __forceinline__ void d_load1(const T *__restrict__ base, int e, v16i &R)
+{
+  const T *p = d_uniform_ptr(base, e);
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(R) : "s"(p) : "memory");
+}
+// two records in flight together (the Ewald walk's two segment cursors)
+template <class T>
+__device__ __forceinline__ void d_load2(const T *__restrict__ base, int ea, v16i &A, int eb, v16i &B)
+{
+  const T *pa = d_uniform_ptr(base, ea), *pb = d_uniform_ptr(base, eb);
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(A), "=&s"(B)
+               : "s"(pa), "s"(pb)
+               : "memory");
+}
+// Touch record `e` so that its cache line is on its way into the scalar cache: one dword into a
+// scratch SGPR.  This is the one deliberately asynchronous load: the scratch register is an in/out
+// operand of every later wait (d_load1_touch, d_drain_touch), nothing else may use it in between,
+// and tests/test_abi_and_host.py checks the generated code for exactly that.
 template <class T>
 __device__ __forceinline__ void d_touch(const T *__restrict__ base, int e, int &scratch)
 {
-  unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
-  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
-  unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
-  const T *p = reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+  const T *p = d_uniform_ptr(base, e);
   asm volatile("s_load_dword %0, %1, 0x0" : "=s"(scratch) : "s"(p) : "memory");
 }
-__device__ __forceinline__ void d_wait_touch(v16i &A, int &s1, int &s2)
+// load record `e` and wait for it and for the outstanding touches
+template <class T>
+__device__ __forceinline__ void d_load1_touch(const T *__restrict__ base, int e, v16i &R, int &s1,
+                                              int &s2)
 {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(s1), "+s"(s2) : : "memory");
+  const T *p = d_uniform_ptr(base, e);
+  asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=s"(R), "+s"(s1), "+s"(s2)
+               : "s"(p)
+               : "memory");
 }
 __device__ __forceinline__ void d_drain_touch(int &s1, int &s2)
 {
   asm volatile("s_waitcnt lgkmcnt(0) ; drain-touches" : "+s"(s1), "+s"(s2) : : "memory");
-}
-__device__ __forceinline__ void d_wait1(v16i &A)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
-}
-__device__ __forceinline__ void d_wait2(v16i &A, v16i &B)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) : : "memory");
 }
 
 // 1/sqrt(x) to full fp64 precision from the hardware seed (v_rsq_f64, ~2^-23 relative) with one
@@ -336,8 +351,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
       if(need_cold != 0)
         {
           v16i C;
-          d_issue_load(cold, e, C);
-          d_wait1(C);
+          d_load1(cold, e, C);
           const double cx = d_f64(C, 0), cy = d_f64(C, 1), cz = d_f64(C, 2), len = d_f64(C, 3);
           const double len06 = d_f64(C, 4);
           const double c0 = cx - W.pos_x, c1 = cy - W.pos_y, c2 = cz - W.pos_z;
@@ -478,8 +492,7 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
         {
           int ea = __builtin_amdgcn_readfirstlane(sg.anc[c.kseg * GHIP_MAXANC + a]);
           v16i H;
-          d_issue_load(hot, ea, H);
-          d_wait1(H);
+          d_load1(hot, ea, H);
           d_walk_element<MODE, PERIODIC, UNEQUAL, false>(ea, H, cold, p, srtab, ewtab, W, my_skip);
           steps++;
         }
@@ -557,8 +570,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       while(liveA)
         {
           v16i HA;
-          d_issue_load(hot, A.e, HA);
-          d_wait_touch(HA, t1, t2);
+          d_load1_touch(hot, A.e, HA, t1, t2);
           d_touch(hot, A.e + 1, t1);
           d_touch(hot, HA[12], t2);
           steps++;
@@ -593,9 +605,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       while(liveA && liveB)
         {
           v16i HA, HB;
-          d_issue_load(hot, A.e, HA);
-          d_issue_load(hot, B.e, HB);
-          d_wait2(HA, HB);
+          d_load2(hot, A.e, HA, B.e, HB);
           steps += 2;
           A.e = __builtin_amdgcn_readfirstlane(
             d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
@@ -623,8 +633,7 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       while(liveA)
         {
           v16i HA;
-          d_issue_load(hot, A.e, HA);
-          d_wait1(HA);
+          d_load1(hot, A.e, HA);
           steps++;
           A.e = __builtin_amdgcn_readfirstlane(
             d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
