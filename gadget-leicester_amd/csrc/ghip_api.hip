@@ -407,6 +407,7 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
       UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
       UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
       UNPACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
+      UNPACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
     }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));

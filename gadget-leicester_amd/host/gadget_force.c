@@ -27,6 +27,13 @@ struct global_data_all_processes All;
 int NumPart = 0, N_gas = 0;
 int FirstActiveParticle = -1, *NextActiveParticle = NULL;
 int TreeReconstructFlag = 1;
+int TimeBinCount[TIMEBINS], TimeBinCountSph[TIMEBINS], TimeBinActive[TIMEBINS];
+int FirstInTimeBin[TIMEBINS], LastInTimeBin[TIMEBINS];
+int *NextInTimeBin, *PrevInTimeBin;
+int Flag_FullStep;
+static double dt_displacement = 0; /* timestep.c:17 */
+static const double *KickTabGrav, *KickTabHydro;
+static double KickLogBegin, KickLogMax;
 double DomainCorner[3], DomainCenter[3], DomainLen = 0, DomainFac = 0;
 int *Ngblist = NULL;
 struct gravdata_in *GravDataGet = NULL;
@@ -534,6 +541,177 @@ void hydro_force(void)
     return;
   Phase = 0;
   CPU_Step_Hydro += wallclock() - t0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row N1: timestep criterion + kick
+ * ---------------------------------------------------------------------------------------- */
+void gadget_force_set_kick_tables(const double *gravkick, const double *hydrokick,
+                                  double logTimeBegin, double logTimeMax)
+{
+  KickTabGrav = gravkick;
+  KickTabHydro = hydrokick;
+  KickLogBegin = logTimeBegin;
+  KickLogMax = logTimeMax;
+}
+
+/* timestep.c:1226-1246 */
+int get_timestep_bin(int ti_step)
+{
+  int bin = -1;
+  if(ti_step == 0)
+    return 0;
+  if(ti_step == 1)
+    {
+      printf("time-step of integer size 1 not allowed\n");
+      endrun(112313);
+    }
+  while(ti_step)
+    {
+      bin++;
+      ti_step >>= 1;
+    }
+  return bin;
+}
+
+/* timestep.c:1125-1224: the per-type sums come from the device (ghip_velocity_moments replaces the
+ * particle loop and the MPI_Allreduce of a single-rank run), the rest is the reference's host math */
+void find_dt_displacement_constraint(double hfac)
+{
+  dt_displacement = All.MaxSizeTimestep;
+  if(!All.ComovingIntegrationOn)
+    return;
+  if(need_ctx("find_dt_displacement_constraint"))
+    return;
+  if(!DeviceFresh && upload_particles())
+    return;
+  double v_sum[6], min_mass[6];
+  long long count_sum[6];
+  if(chk(ghip_velocity_moments(Ctx, v_sum, min_mass, count_sum), "ghip_velocity_moments"))
+    return;
+  for(int type = 0; type < 6; type++)
+    if(count_sum[type] > 0)
+      {
+        double dmean, dt;
+        if(type == 0 || (type == 4 && All.StarformationOn))
+          dmean = pow(min_mass[type] / (All.OmegaBaryon * 3 * All.Hubble * All.Hubble / (8 * M_PI * All.G)),
+                      1.0 / 3);
+        else
+          dmean = pow(min_mass[type] / ((All.Omega0 - All.OmegaBaryon) * 3 * All.Hubble * All.Hubble /
+                                        (8 * M_PI * All.G)),
+                      1.0 / 3);
+        dt = All.MaxRMSDisplacementFac * hfac * dmean / sqrt(v_sum[type] / count_sum[type]);
+        if(dt < dt_displacement)
+          dt_displacement = dt;
+      }
+}
+
+/* rebuild the linked lists of the time bins from P[].TimeBin, in index order
+ * (reconstruct_timebins(), timestep.c / domain.c) */
+static void rebuild_timebin_lists(void)
+{
+  for(int b = 0; b < TIMEBINS; b++)
+    {
+      TimeBinCount[b] = TimeBinCountSph[b] = 0;
+      FirstInTimeBin[b] = LastInTimeBin[b] = -1;
+    }
+  for(int i = 0; i < NumPart; i++)
+    {
+      int bin = P[i].TimeBin;
+      if(NextInTimeBin && PrevInTimeBin)
+        {
+          if(TimeBinCount[bin] > 0)
+            {
+              PrevInTimeBin[i] = LastInTimeBin[bin];
+              NextInTimeBin[i] = -1;
+              NextInTimeBin[LastInTimeBin[bin]] = i;
+              LastInTimeBin[bin] = i;
+            }
+          else
+            {
+              FirstInTimeBin[bin] = LastInTimeBin[bin] = i;
+              PrevInTimeBin[i] = NextInTimeBin[i] = -1;
+            }
+        }
+      TimeBinCount[bin]++;
+      if(P[i].Type == 0)
+        TimeBinCountSph[bin]++;
+    }
+}
+
+/* timestep.c:29-362 for the minimal flag set (no PMGRID long-range kick, no MAKEGLASS); the
+ * particle loop :142-260 with get_timestep and do_the_kick runs on the device */
+void advance_and_find_timesteps(void)
+{
+  if(need_ctx("advance_and_find_timesteps"))
+    return;
+  if(All.TypeOfTimestepCriterion != 0)
+    {
+      endrun(888); /* timestep.c:726 */
+      return;
+    }
+  double hubble_a = 1, atime = 1;
+  if(All.ComovingIntegrationOn)
+    {
+      hubble_a = hubble_function(All.Time);
+      atime = All.Time;
+      if(!KickTabGrav || !KickTabHydro)
+        {
+          snprintf(ErrBuf, sizeof(ErrBuf),
+                   "advance_and_find_timesteps: comoving kicks need gadget_force_set_kick_tables()");
+          fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+          endrun(90002);
+          return;
+        }
+    }
+  /* the accelerations of this step are on the device (Phase 0 after hydro_force); velocities and
+   * entropies are the host's: make the device image current */
+  if(!DeviceFresh && upload_particles())
+    return;
+  if(Flag_FullStep || dt_displacement == 0)
+    find_dt_displacement_constraint(hubble_a * atime * atime);
+  int nact = collect_active(0);
+  if(nact < 0)
+    return;
+  if(chk(ghip_set_active(Ctx, nact == NumPart ? NULL : ActiveBuf, nact == NumPart ? 0 : nact),
+         "ghip_set_active"))
+    return;
+  ghip_kick_params k;
+  memset(&k, 0, sizeof(k));
+  k.Ti_Current = All.Ti_Current;
+  k.Timebase_interval = All.Timebase_interval;
+  k.ComovingIntegrationOn = All.ComovingIntegrationOn;
+  k.Time = All.Time;
+  k.hubble_a = hubble_a;
+  k.ErrTolIntAccuracy = All.ErrTolIntAccuracy;
+  k.CourantFac = All.CourantFac;
+  k.MaxSizeTimestep = All.MaxSizeTimestep;
+  k.MinSizeTimestep = All.MinSizeTimestep;
+  k.dt_displacement = dt_displacement;
+  for(int t = 0; t < 6; t++)
+    k.SofteningTable[t] = All.SofteningTable[t];
+  k.MinEgySpec = All.MinEgySpec;
+  for(int b = 0; b < TIMEBINS; b++)
+    if(TimeBinActive[b])
+      k.TimeBinActive |= 1u << b;
+  k.logTimeBegin = KickLogBegin;
+  k.logTimeMax = KickLogMax;
+  k.GravKickTable = KickTabGrav;
+  k.HydroKickTable = KickTabHydro;
+  long long cnt[32], sph[32];
+  int rc = ghip_advance_timesteps(Ctx, &k, cnt, sph);
+  if(rc == GHIP_ETIMESTEP)
+    {
+      endrun(ghip_timestep_endrun_code(Ctx)); /* the reference's own code: 888, 818, 112313 */
+      return;
+    }
+  if(chk(rc, "ghip_advance_timesteps"))
+    return;
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  if(chk(ghip_download_aos_kick(Ctx, P, SphP, &lay), "ghip_download_aos_kick"))
+    return;
+  rebuild_timebin_lists();
 }
 
 /* ------------------------------------------------------------------------------------------

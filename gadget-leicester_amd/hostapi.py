@@ -54,7 +54,12 @@ class AllStruct(C.Structure):
                 ("SofteningTable", C.c_double * 6), ("ForceSoftening", C.c_double * 6),
                 ("Rcut", C.c_double * 2), ("Asmth", C.c_double * 2),
                 ("TotNumOfForces", C.c_longlong), ("BunchSize", C.c_int),
-                ("BufferSize", C.c_double)]
+                ("BufferSize", C.c_double),
+                ("ErrTolIntAccuracy", C.c_double), ("CourantFac", C.c_double),
+                ("MaxSizeTimestep", C.c_double), ("MinSizeTimestep", C.c_double),
+                ("MaxRMSDisplacementFac", C.c_double), ("OmegaBaryon", C.c_double),
+                ("MinEgySpec", C.c_double), ("TypeOfTimestepCriterion", C.c_int),
+                ("StarformationOn", C.c_int)]
 
 
 class Config(C.Structure):
@@ -74,7 +79,10 @@ EXPORTS = ["gadget_force_init", "gadget_force_finalize", "gadget_force_last_erro
            "peano_hilbert_key", "morton_key", "hubble_function",
            "P", "SphP", "All", "NumPart", "N_gas", "FirstActiveParticle", "NextActiveParticle",
            "TreeReconstructFlag", "DomainCorner", "DomainCenter", "DomainLen", "DomainFac",
-           "Ngblist", "GravDataGet", "GravDataResult"]
+           "Ngblist", "GravDataGet", "GravDataResult",
+           "advance_and_find_timesteps", "find_dt_displacement_constraint", "get_timestep_bin",
+           "gadget_force_set_kick_tables", "TimeBinCount", "TimeBinCountSph", "TimeBinActive",
+           "FirstInTimeBin", "LastInTimeBin", "NextInTimeBin", "PrevInTimeBin", "Flag_FullStep"]
 
 _LIB = None
 

@@ -144,6 +144,10 @@ struct global_data_all_processes
   long long TotNumOfForces;
   int BunchSize;
   double BufferSize;
+  /* "next" row N1: timestep criterion + kick (timestep.c) */
+  double ErrTolIntAccuracy, CourantFac, MaxSizeTimestep, MinSizeTimestep, MaxRMSDisplacementFac;
+  double OmegaBaryon, MinEgySpec;
+  int TypeOfTimestepCriterion, StarformationOn;
 };
 
 /* gravdata_in / gravdata_out, allvars.h:1690-1716 (mode == 1 records) */
@@ -184,6 +188,14 @@ extern int ThisTask, NTask;
 extern double CPU_Step_Treewalk, CPU_Step_Treebuild, CPU_Step_Density, CPU_Step_Hydro,
   CPU_Step_Hmaxupdate; /* the CPU_Step[] buckets the path fills (allvars.h:205-238) */
 
+/* time bins (allvars.h:337-346) and the step flag of run.c; TIMEBINS = 29 */
+#define TIMEBINS 29
+#define TIMEBASE (1 << TIMEBINS)
+extern int TimeBinCount[TIMEBINS], TimeBinCountSph[TIMEBINS], TimeBinActive[TIMEBINS];
+extern int FirstInTimeBin[TIMEBINS], LastInTimeBin[TIMEBINS];
+extern int *NextInTimeBin, *PrevInTimeBin; /* sized MaxPart by the host */
+extern int Flag_FullStep;
+
 /* ---- library management (no counterpart in the reference) ---- */
 int gadget_force_init(const struct gadget_force_config *cfg);  /* 0 or a GHIP_E* code */
 void gadget_force_finalize(void);
@@ -193,6 +205,11 @@ void gadget_force_layout(ghip_layout *lay);   /* offsets of the structs above */
 /* endrun(code) handler: default prints "task %d: endrun called with an error level of %d" and
  * abort()s like MPI_Abort would; tests install a recording handler. */
 void gadget_force_set_endrun(void (*handler)(int code));
+/* the comoving kick-factor tables of driftfac.c (GravKickTable / HydroKickTable, 1000 entries each,
+ * built by the host's init_drift_table) and their log(a) range; needed when
+ * All.ComovingIntegrationOn is set */
+void gadget_force_set_kick_tables(const double *gravkick, const double *hydrokick,
+                                  double logTimeBegin, double logTimeMax);
 /* tell the glue that the host changed P/SphP outside the four drivers */
 void gadget_force_mark_dirty(void);
 
@@ -207,6 +224,10 @@ void density(void);
 int density_isactive(int n);
 void force_update_hmax(void);
 void hydro_force(void);
+/* "next" row N1 (timestep.c:29, 1125, 1226): the particle loop runs on the device */
+void advance_and_find_timesteps(void);
+void find_dt_displacement_constraint(double hfac);
+int get_timestep_bin(int ti_step);
 
 int force_treeevaluate(int target, int mode, int *nexport, int *nsend_local);
 int force_treeevaluate_shortrange(int target, int mode, int *nexport, int *nsend_local);

@@ -745,6 +745,71 @@ def test_timestep_and_kick_parity(comoving, subset):
     assert fp.stats()["ms_kick"] > 0
 
 
+def test_advance_and_find_timesteps_on_aos_records():
+    """The host mirror advance_and_find_timesteps() (timestep.c:29) on P[]/SphP[] records: kick
+    results, TimeBin[] and the rebuilt bin lists against the CPU restatement."""
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    pr = Problem(ng=8, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    st, par, _ = _kick_case(pr, False)
+    host, P, S = _host_problem(pr, H, 1)
+    L = host.L
+    P["GravAccel"], P["TimeBin"], P["Ti_begstep"] = st["grav"], st["timebin"], st["ti_begstep"]
+    S["HydroAccel"], S["MaxSignalVel"], S["Density"], S["Pressure"] = \
+        st["hyd"], st["vsig"], st["dens"], st["pres"]
+    S["Hsml"], S["Entropy"], S["DtEntropy"] = st["hs"], st["entropy"], st["dtentropy"]
+    L.gadget_force_mark_dirty()
+    A = host.All
+    A.Ti_Current, A.Timebase_interval = par["Ti_Current"], par["Timebase_interval"]
+    A.ErrTolIntAccuracy, A.CourantFac = par["ErrTolIntAccuracy"], par["CourantFac"]
+    A.MaxSizeTimestep, A.MinSizeTimestep = par["MaxSizeTimestep"], par["MinSizeTimestep"]
+    A.MinEgySpec, A.TypeOfTimestepCriterion = 0.0, 0
+    par["dt_displacement"] = par["MaxSizeTimestep"]     # not comoving: timestep.c:1133
+    tba = (C.c_int * 29).in_dll(L, "TimeBinActive")
+    for b in range(29):
+        tba[b] = (par["TimeBinActive"] >> b) & 1
+    nxt = np.full(n, -1, np.int32)
+    prv = np.full(n, -1, np.int32)
+    C.c_void_p.in_dll(L, "NextInTimeBin").value = nxt.ctypes.data
+    C.c_void_p.in_dll(L, "PrevInTimeBin").value = prv.ctypes.data
+    C.c_int.in_dll(L, "Flag_FullStep").value = 1
+    active = np.sort(np.random.default_rng(9).choice(n, n // 2, replace=False)).astype(np.int32)
+    host.set_active(active)
+    vel0 = P["Vel"].copy()
+    L.advance_and_find_timesteps()
+    assert host.endrun_codes == []
+    soft = np.array(list(A.SofteningTable))
+    want = O.advance_timesteps(_fill(O.KickParams(), par, soft), pr.ic["type"], vel0, st["grav"],
+                               st["hyd"], pr.velpred, st["entropy"], st["dtentropy"], st["dens"],
+                               st["pres"], st["hs"], st["vsig"], st["timebin"], st["ti_begstep"],
+                               active=active)
+    assert want["rc"] == 0
+    assert np.array_equal(P["TimeBin"], want["timebin"])
+    assert np.array_equal(P["Ti_begstep"], want["ti_begstep"])
+    assert np.array_equal(P["Vel"], want["vel"])
+    assert np.array_equal(S["VelPred"], want["velpred"])
+    assert np.array_equal(S["Entropy"], want["entropy"])
+    assert np.array_equal(S["DtEntropy"], want["dtentropy"])
+    cnt = np.array((C.c_int * 29).in_dll(L, "TimeBinCount"))
+    sph = np.array((C.c_int * 29).in_dll(L, "TimeBinCountSph"))
+    assert np.array_equal(cnt, want["bincount"][:29]) and np.array_equal(sph, want["bincount_sph"][:29])
+    # the linked lists thread every bin in index order
+    first = np.array((C.c_int * 29).in_dll(L, "FirstInTimeBin"))
+    for b in np.where(cnt > 0)[0]:
+        chain, i = [], first[b]
+        while i >= 0:
+            chain.append(i)
+            i = nxt[i]
+        assert np.array_equal(chain, np.where(P["TimeBin"] == b)[0])
+    # members the kick does not own survive the round trip
+    assert np.array_equal(P["Pos"], pr.ic["pos"]) and np.array_equal(P["GravAccel"], st["grav"])
+    # a criterion failure ends in the reference's endrun code
+    A.MinSizeTimestep = 1.0
+    L.advance_and_find_timesteps()
+    assert host.endrun_codes == [888]
+    host.close()
+
+
 def test_timestep_failure_reports_the_reference_endrun_code():
     B = bindings()
     pr = Problem(ng=6, gas=True, periodic=1)
