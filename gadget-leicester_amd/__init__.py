@@ -18,7 +18,7 @@ LIBGHIP = os.path.join(PKG_DIR, "libghip.so")
 LIBHOST = os.path.join(PKG_DIR, "libgadget_force.so")
 
 HIP_SOURCES = ["ghip_api.hip", "ghip_tree.hip", "ghip_gravity.hip", "ghip_sph.hip",
-               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip"]
+               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 

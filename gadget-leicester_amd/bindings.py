@@ -78,6 +78,24 @@ class KickParams(C.Structure):
                 ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p)]
 
 
+class NodeLayout(C.Structure):
+    """ghip_node_layout: byte offsets of struct NODE / struct extNODE (allvars.h:1847-1916)"""
+    _fields_ = [(k, C.c_int) for k in
+                ("node_stride", "n_len", "n_center", "n_s", "n_mass", "n_bitflags", "n_sibling",
+                 "n_nextnode", "n_father", "n_ti_current", "ext_stride", "e_dp", "e_vs", "e_vmax",
+                 "e_divvmax", "e_hmax", "e_ti_lastkicked", "e_flag")]
+
+
+# struct NODE / struct extNODE of the minimal periodic flag set (88 / 80 bytes, SURVEY.md 8a a3)
+NODE_DTYPE = np.dtype({"names": ["len", "center", "s", "mass", "bitflags", "sibling", "nextnode",
+                                 "father", "Ti_current"],
+                       "formats": ["f8", ("f8", 3), ("f8", 3), "f8", "u4", "i4", "i4", "i4", "i4"],
+                       "offsets": [0, 8, 32, 56, 64, 68, 72, 76, 80], "itemsize": 88})
+EXTNODE_DTYPE = np.dtype({"names": ["dp", "vs", "vmax", "divVmax", "hmax", "Ti_lastkicked", "Flag"],
+                          "formats": [("f8", 3), ("f8", 3), "f8", "f8", "f8", "i4", "i4"],
+                          "offsets": [0, 24, 48, 56, 64, 72, 76], "itemsize": 80})
+
+
 class Stats(C.Structure):
     _fields_ = [("grav_interactions", C.c_longlong), ("grav_targets", C.c_longlong),
                 ("ewald_interactions", C.c_longlong), ("dens_neighbours", C.c_longlong),
@@ -110,7 +128,8 @@ EXPORTS = [
     "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
-    "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick"]
+    "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
+    "ghip_tree_export"]
 
 
 def lib():
@@ -158,6 +177,8 @@ def lib():
         L.ghip_timestep_endrun_code.argtypes = [vp]
         L.ghip_velocity_moments.argtypes = [vp, vp, vp, vp]
         L.ghip_download_aos_kick.argtypes = [vp, vp, vp, C.POINTER(Layout)]
+        L.ghip_tree_export.argtypes = [vp, C.POINTER(NodeLayout), C.c_int, C.c_int, C.c_int, vp, vp,
+                                       vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ghip_shard_pack.argtypes = [vp, C.c_int, vp]
         L.ghip_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -309,6 +330,33 @@ class ForcePath:
                 e.endrun = self.L.ghip_timestep_endrun_code(self.h)
                 raise
         return np.array(cnt[:], dtype=np.int64), np.array(sph[:], dtype=np.int64)
+
+    def tree_export(self, maxpart=None, ti_current=0, unequal=0, max_nodes=None):
+        """ghip_tree_export into numpy records of the minimal-flag-set NODE / extNODE layout;
+        returns (Nodes, Extnodes, Nextnode, Father) with Nodes[k] = node maxpart + k."""
+        maxpart = self.n if maxpart is None else int(maxpart)
+        max_nodes = int(2.0 * maxpart + 16) if max_nodes is None else int(max_nodes)
+        lay = NodeLayout()
+        lay.node_stride = NODE_DTYPE.itemsize
+        for name, key in (("len", "n_len"), ("center", "n_center"), ("s", "n_s"), ("mass", "n_mass"),
+                          ("bitflags", "n_bitflags"), ("sibling", "n_sibling"),
+                          ("nextnode", "n_nextnode"), ("father", "n_father"),
+                          ("Ti_current", "n_ti_current")):
+            setattr(lay, key, NODE_DTYPE.fields[name][1])
+        lay.ext_stride = EXTNODE_DTYPE.itemsize
+        for name, key in (("dp", "e_dp"), ("vs", "e_vs"), ("vmax", "e_vmax"),
+                          ("divVmax", "e_divvmax"), ("hmax", "e_hmax"),
+                          ("Ti_lastkicked", "e_ti_lastkicked"), ("Flag", "e_flag")):
+            setattr(lay, key, EXTNODE_DTYPE.fields[name][1])
+        nodes = np.zeros(max_nodes, NODE_DTYPE)
+        ext = np.zeros(max_nodes, EXTNODE_DTYPE)
+        nxt = np.full(maxpart, -1, np.int32)
+        fat = np.full(maxpart, -1, np.int32)
+        nn = C.c_int(0)
+        self._chk(self.L.ghip_tree_export(self.h, C.byref(lay), maxpart, int(ti_current),
+                                          int(unequal), _ptr(nodes), _ptr(ext), _ptr(nxt), _ptr(fat),
+                                          max_nodes, C.byref(nn)))
+        return nodes[:nn.value], ext[:nn.value], nxt, fat
 
     def velocity_moments(self):
         v2 = (C.c_double * 6)()

@@ -27,6 +27,10 @@ struct global_data_all_processes All;
 int NumPart = 0, N_gas = 0;
 int FirstActiveParticle = -1, *NextActiveParticle = NULL;
 int TreeReconstructFlag = 1;
+struct NODE *Nodes_base, *Nodes;
+struct extNODE *Extnodes_base, *Extnodes;
+int *Nextnode, *Father;
+int MaxNodes, Numnodestree;
 int TimeBinCount[TIMEBINS], TimeBinCountSph[TIMEBINS], TimeBinActive[TIMEBINS];
 int FirstInTimeBin[TIMEBINS], LastInTimeBin[TIMEBINS];
 int *NextInTimeBin, *PrevInTimeBin;
@@ -386,11 +390,43 @@ int force_treebuild(int npart, void *mp)
     return -1;
   ghip_sync(Ctx);
   TreeOnDevice = 1;
-  CPU_Step_Treebuild += wallclock() - t0;
   ghip_stats st;
   ghip_get_stats(Ctx, &st);
   (void) npart;
-  return st.tree_nodes;
+  Numnodestree = st.tree_nodes;
+  if(Nodes_base && Extnodes_base && Nextnode && Father)
+    {
+      /* "next" row N2: the host's own walks (potential.c, ...) get the tree in their arrays */
+      ghip_node_layout nl;
+      memset(&nl, 0xff, sizeof(nl));
+      nl.node_stride = (int) sizeof(struct NODE);
+      nl.n_len = (int) offsetof(struct NODE, len);
+      nl.n_center = (int) offsetof(struct NODE, center);
+      nl.n_s = (int) offsetof(struct NODE, u.d.s);
+      nl.n_mass = (int) offsetof(struct NODE, u.d.mass);
+      nl.n_bitflags = (int) offsetof(struct NODE, u.d.bitflags);
+      nl.n_sibling = (int) offsetof(struct NODE, u.d.sibling);
+      nl.n_nextnode = (int) offsetof(struct NODE, u.d.nextnode);
+      nl.n_father = (int) offsetof(struct NODE, u.d.father);
+      nl.n_ti_current = (int) offsetof(struct NODE, Ti_current);
+      nl.ext_stride = (int) sizeof(struct extNODE);
+      nl.e_dp = (int) offsetof(struct extNODE, dp);
+      nl.e_vs = (int) offsetof(struct extNODE, vs);
+      nl.e_vmax = (int) offsetof(struct extNODE, vmax);
+      nl.e_divvmax = (int) offsetof(struct extNODE, divVmax);
+      nl.e_hmax = (int) offsetof(struct extNODE, hmax);
+      nl.e_ti_lastkicked = (int) offsetof(struct extNODE, Ti_lastkicked);
+      nl.e_flag = (int) offsetof(struct extNODE, Flag);
+      int nn = 0;
+      if(chk(ghip_tree_export(Ctx, &nl, All.MaxPart, All.Ti_Current, Cfg.unequal_softenings,
+                              Nodes_base, Extnodes_base, Nextnode, Father, MaxNodes, &nn),
+             "ghip_tree_export"))
+        return -1;
+      Nodes = Nodes_base - All.MaxPart;       /* forcetree.c:4585-4590 */
+      Extnodes = Extnodes_base - All.MaxPart;
+    }
+  CPU_Step_Treebuild += wallclock() - t0;
+  return Numnodestree;
 }
 
 /* forcetree.c:4402-4527 */

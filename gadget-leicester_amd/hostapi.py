@@ -82,7 +82,9 @@ EXPORTS = ["gadget_force_init", "gadget_force_finalize", "gadget_force_last_erro
            "Ngblist", "GravDataGet", "GravDataResult",
            "advance_and_find_timesteps", "find_dt_displacement_constraint", "get_timestep_bin",
            "gadget_force_set_kick_tables", "TimeBinCount", "TimeBinCountSph", "TimeBinActive",
-           "FirstInTimeBin", "LastInTimeBin", "NextInTimeBin", "PrevInTimeBin", "Flag_FullStep"]
+           "FirstInTimeBin", "LastInTimeBin", "NextInTimeBin", "PrevInTimeBin", "Flag_FullStep",
+           "Nodes_base", "Nodes", "Extnodes_base", "Extnodes", "Nextnode", "Father", "MaxNodes",
+           "Numnodestree"]
 
 _LIB = None
 

@@ -164,6 +164,37 @@ struct gravdata_out
   int Ninteractions;
 };
 
+/* struct NODE / struct extNODE (allvars.h:1847-1916) of the minimal flag set: 88 / 80 bytes */
+struct NODE
+{
+  MyFloat len;
+  MyFloat center[3];
+  union
+  {
+    int suns[8];
+    struct
+    {
+      MyFloat s[3];
+      MyFloat mass;
+      unsigned int bitflags;
+      int sibling;
+      int nextnode;
+      int father;
+    } d;
+  } u;
+  int Ti_current;
+};
+struct extNODE
+{
+  MyLongDouble dp[3];
+  MyFloat vs[3];
+  MyFloat vmax;
+  MyFloat divVmax;
+  MyFloat hmax;
+  int Ti_lastkicked;
+  int Flag;
+};
+
 /* compile-time switches of the reference that this library takes at run time */
 struct gadget_force_config
 {
@@ -187,6 +218,14 @@ extern struct gravdata_out *GravDataResult;
 extern int ThisTask, NTask;
 extern double CPU_Step_Treewalk, CPU_Step_Treebuild, CPU_Step_Density, CPU_Step_Hydro,
   CPU_Step_Hmaxupdate; /* the CPU_Step[] buckets the path fills (allvars.h:205-238) */
+
+/* the host's tree arrays (allvars.h:1880-1916, forcetree.c:4560-4600 force_treeallocate).  When
+ * Nodes_base is set, force_treebuild() also exports the device-built tree into them ("next" row
+ * N2): Nodes = Nodes_base - All.MaxPart as in the reference, Numnodestree = number of nodes. */
+extern struct NODE *Nodes_base, *Nodes;
+extern struct extNODE *Extnodes_base, *Extnodes;
+extern int *Nextnode, *Father;
+extern int MaxNodes, Numnodestree;
 
 /* time bins (allvars.h:337-346) and the step flag of run.c; TIMEBINS = 29 */
 #define TIMEBINS 29

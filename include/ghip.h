@@ -154,6 +154,15 @@ typedef struct
   const double *GravKickTable, *HydroKickTable;   /* host, 1000 entries each; comoving only */
 } ghip_kick_params;
 
+/* "next" row N2: byte offsets of struct NODE / struct extNODE (allvars.h:1847-1916) as the host
+ * was compiled; -1 = member absent / not wanted.  Vectors are 3 consecutive doubles. */
+typedef struct
+{
+  int node_stride, n_len, n_center, n_s, n_mass, n_bitflags, n_sibling, n_nextnode, n_father,
+    n_ti_current;
+  int ext_stride, e_dp, e_vs, e_vmax, e_divvmax, e_hmax, e_ti_lastkicked, e_flag;
+} ghip_node_layout;
+
 /* work counters of the last phase, counted exactly as the reference counts them
  * (SURVEY.md 8d): used for roofline.achieved */
 typedef struct
@@ -229,6 +238,16 @@ int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_mass[6], lo
 /* pack the kick's results (Vel, TimeBin, Ti_begstep; VelPred, Entropy, DtEntropy) into the device
  * image of the records and copy the blocks to the host */
 int ghip_download_aos_kick(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay);
+
+/* ---- "next" row N2: export the device-built gravity tree in the reference's representation
+ * (what force_treebuild + force_update_node_recursive leave behind, forcetree.c:67-872): record k
+ * of Nodes_base / Extnodes_base is node MaxPart + k (the root is node MaxPart), Nextnode[] and
+ * Father[] are filled for the particles [0, numpart).  Needs a built tree and the VEL, HSML,
+ * DIVVEL, TYPE fields (for vs, vmax, hmax, divVmax).  Single-rank semantics: no TOPLEVEL /
+ * pseudo-particle entries. ---- */
+int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int MaxPart, int Ti_Current,
+                     int unequal_softenings, void *Nodes_base, void *Extnodes_base, int *Nextnode,
+                     int *Father, int max_nodes, int *numnodes);
 
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],

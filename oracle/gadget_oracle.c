@@ -524,6 +524,22 @@ void orc_tree_dump(const orc_tree *t, double *len, double *center3, double *s3, 
     }
 }
 
+/* the extNODE members and the softening flags of the nodes (forcetree.c:612-700, 830-846) */
+void orc_tree_dump_ext(const orc_tree *t, double *vs3, double *vmax, double *divvmax,
+                       double *maxsoft, int *mixedsoft)
+{
+  for(int k = 0; k < t->numnodes; k++)
+    {
+      const onode *nd = &t->nodes[k];
+      for(int j = 0; j < 3; j++)
+        vs3[3 * k + j] = nd->vs[j];
+      vmax[k] = nd->vmax;
+      divvmax[k] = nd->divVmax;
+      maxsoft[k] = nd->maxsoft;
+      mixedsoft[k] = nd->mixedsoft;
+    }
+}
+
 void orc_tree_dump_particles(const orc_tree *t, int *nextnode, int *father)
 {
   memcpy(nextnode, t->nextnode, (size_t) t->n * sizeof(int));

@@ -51,6 +51,8 @@ int orc_tree_numnodes(const orc_tree *t);
 /* node dump for tests: arrays sized numnodes; index k is node (n + k) */
 void orc_tree_dump(const orc_tree *t, double *len, double *center3, double *s3, double *mass,
                    int *sibling, int *nextnode, int *father, int *multi, double *hmax);
+void orc_tree_dump_ext(const orc_tree *t, double *vs3, double *vmax, double *divvmax,
+                       double *maxsoft, int *mixedsoft);
 /* Nextnode[] and Father[] for particles (size n) */
 void orc_tree_dump_particles(const orc_tree *t, int *nextnode, int *father);
 /* force_update_hmax (forcetree.c:1661-1786): raise hmax/divVmax up the Father chain */

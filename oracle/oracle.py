@@ -59,6 +59,7 @@ def lib():
         L.orc_tree_free.argtypes = [C.c_void_p]
         L.orc_tree_numnodes.argtypes = [C.c_void_p]
         L.orc_tree_dump.argtypes = [C.c_void_p] * 10
+        L.orc_tree_dump_ext.argtypes = [C.c_void_p] * 6
         L.orc_tree_dump_particles.argtypes = [C.c_void_p] * 3
         L.orc_update_hmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_gravity.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -185,6 +186,10 @@ class Tree:
         lib().orc_tree_dump(self.h, *[_p(out[x]) for x in
                                       ("len", "center", "s", "mass", "sibling", "nextnode",
                                        "father", "multi", "hmax")])
+        out.update(vs=np.zeros((k, 3)), vmax=np.zeros(k), divvmax=np.zeros(k), maxsoft=np.zeros(k),
+                   mixedsoft=np.zeros(k, np.int32))
+        lib().orc_tree_dump_ext(self.h, *[_p(out[x]) for x in
+                                          ("vs", "vmax", "divvmax", "maxsoft", "mixedsoft")])
         pn = np.zeros(self.n, np.int32)
         pf = np.zeros(self.n, np.int32)
         lib().orc_tree_dump_particles(self.h, _p(pn), _p(pf))

@@ -69,6 +69,82 @@ def test_gas_tree_hmax_is_the_maximum_smoothing_length_below():
         assert aux[e] == hs[lk[e, 2]:lk[e, 2] + lk[e, 3]].max()
 
 
+@pytest.mark.parametrize("unequal", [0, 1])
+def test_exported_tree_is_the_reference_representation(unequal):
+    """"next" row N2: ghip_tree_export hands the device-built tree back as Nodes[] / Extnodes[] /
+    Nextnode[] / Father[].  Cells are matched by geometry (node numbering is pre-order on the
+    device, insertion order in the reference); after that relabelling every member and every link
+    must be the insertion tree's: s, mass, vs, vmax, hmax, divVmax, MULTIPLEPARTICLES and softening
+    flags, sibling / nextnode / father, and the particles' Nextnode / Father."""
+    B = bindings()
+    ic = ics.make_plummer(4000, gas_fraction=0.4)
+    pr = Problem(ic=ic, periodic=0, unequal=bool(unequal))
+    n, ng = pr.n, pr.ngas
+    rng = np.random.default_rng(2)
+    hs = pr.hsml0.copy()
+    hs[:ng] *= 0.5 + rng.random(ng)
+    divv = rng.standard_normal(ng)
+    fp = pr.device()
+    fp.set_field(B.F_HSML, hs)
+    fp.set_field(B.F_DIVVEL, divv)
+    pr.device_tree(fp)
+    maxpart = n + 100                                   # All.MaxPart > NumPart
+    nodes, ext, nxt, fat = fp.tree_export(maxpart=maxpart, ti_current=7, unequal=unequal)
+    dvfull = np.zeros(n)
+    dvfull[:ng] = divv
+    T = O.Tree(ic["pos"], ic["vel"], ic["mass"], ic["type"], pr.force_soft, hsml=hs, divvel=dvfull,
+               extent=pr.extent)
+    od = T.dump()
+    assert len(nodes) == T.numnodes
+    # relabel: oracle node index (n + k) <-> exported node index (maxpart + r), by cell geometry
+    key_g = np.column_stack([nodes["len"], nodes["center"]])
+    key_o = np.column_stack([od["len"], od["center"]])
+    og, oo = np.lexsort(key_g.T[::-1]), np.lexsort(key_o.T[::-1])
+    assert np.array_equal(key_g[og], key_o[oo])          # identical cells, bit for bit
+    o2g = np.empty(T.numnodes, np.int64)
+    o2g[oo] = og                                          # oracle rank k -> exported rank
+
+    def conv(idx):      # oracle element index -> exported element index
+        idx = np.asarray(idx, np.int64)
+        out = idx.copy()
+        isnode = idx >= n
+        out[isnode] = maxpart + o2g[idx[isnode] - n]
+        return out
+
+    g = nodes[o2g]                                        # exported records in oracle order
+    x = ext[o2g]
+    assert np.allclose(g["mass"], od["mass"], rtol=1e-15, atol=0)
+    assert np.allclose(g["s"], od["s"], rtol=1e-14, atol=0)
+    assert np.allclose(x["vs"], od["vs"], rtol=1e-13, atol=1e-16)
+    assert np.array_equal(x["vmax"], od["vmax"])
+    assert np.array_equal(x["hmax"], od["hmax"]) and np.array_equal(x["divVmax"], od["divvmax"])
+    assert (x["hmax"] > 0).any() and (x["divVmax"] > 0).any()
+    assert np.array_equal(x["dp"], np.zeros((T.numnodes, 3)))
+    assert np.all(g["Ti_current"] == 7) and np.all(x["Ti_lastkicked"] == 7)
+    assert np.array_equal((g["bitflags"] >> 7) & 1, od["multi"])
+    if unequal:
+        soft_of_type = pr.force_soft[(g["bitflags"] >> 2) & 7]
+        assert np.array_equal(soft_of_type, od["maxsoft"])
+        assert np.array_equal((g["bitflags"] >> 5) & 1, od["mixedsoft"])
+    else:
+        assert np.all(g["bitflags"] & ~np.uint32(1 << 7) == 0)
+    assert np.array_equal(g["sibling"], conv(od["sibling"]))
+    assert np.array_equal(g["nextnode"], conv(od["nextnode"]))
+    assert np.array_equal(g["father"], conv(od["father"]))
+    assert np.array_equal(nxt[:n], conv(od["p_nextnode"]))
+    assert np.array_equal(fat[:n], conv(od["p_father"]))
+    assert nodes["father"][0] == -1 and nodes["sibling"][0] == -1      # Nodes[MaxPart] is the root
+    # and the exported links thread every particle exactly once from the root
+    seen, no = 0, maxpart
+    while no >= 0:
+        if no < maxpart:
+            seen += 1
+            no = nxt[no]
+        else:
+            no = nodes["nextnode"][no - maxpart]
+    assert seen == n
+
+
 # ------------------------------------------------------------------------------------------------
 # gravity
 # ------------------------------------------------------------------------------------------------
@@ -468,6 +544,55 @@ def test_compute_accelerations_sequence_on_aos_records():
     assert relerr(S["MaxSignalVel"], oh["maxsignalvel"][:ng]) < TOL
     # untouched record members survive the device round trip
     assert np.array_equal(P["ID"], pr.ic["id"]) and np.array_equal(P["Pos"], pr.ic["pos"])
+    host.close()
+
+
+def test_force_treebuild_fills_the_hosts_tree_arrays():
+    """force_treebuild() with Nodes_base/Extnodes_base/Nextnode/Father set ("next" row N2): a plain
+    host-side Barnes-Hut walk over the exported arrays (the loop of force_treeevaluate,
+    forcetree.c:1905-2220, in Python) reproduces the device's own interaction counts."""
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    B = bindings()
+    pr = Problem(ng=8, gas=True, periodic=0)
+    host, P, S = _host_problem(pr, H, 0)
+    L = host.L
+    n = pr.n
+    host.All.MaxPart = n
+    maxnodes = 2 * n
+    nodes = np.zeros(maxnodes, B.NODE_DTYPE)
+    ext = np.zeros(maxnodes, B.EXTNODE_DTYPE)
+    nxt = np.full(n, -1, np.int32)
+    fat = np.full(n, -1, np.int32)
+    for name, arr in (("Nodes_base", nodes), ("Extnodes_base", ext), ("Nextnode", nxt), ("Father", fat)):
+        C.c_void_p.in_dll(L, name).value = arr.ctypes.data
+    C.c_int.in_dll(L, "MaxNodes").value = maxnodes
+    numnodes = L.force_treebuild(n, None)
+    assert host.endrun_codes == [] and numnodes == C.c_int.in_dll(L, "Numnodestree").value > 0
+    assert C.c_void_p.in_dll(L, "Nodes").value == nodes.ctypes.data - n * nodes.itemsize
+    L.gravity_tree()                      # Barnes-Hut pass (OldAcc == 0), GravCost = interactions
+    theta = pr.theta
+    pos, mass = pr.ic["pos"], pr.ic["mass"]
+    for i in (0, 17, n // 2, n - 1):
+        count, no = 0, n
+        while no >= 0:
+            if no < n:                    # particle
+                if mass[no] > 0:
+                    count += 1
+                no = nxt[no]
+                continue
+            nd = nodes[no - n]
+            if not (nd["bitflags"] >> 7) & 1:          # single particle below: open (forcetree.c:1996)
+                no = nd["nextnode"]
+                continue
+            d = nd["s"] - pos[i]
+            r2 = float(d @ d)
+            if nd["len"] * nd["len"] > r2 * theta * theta:
+                no = nd["nextnode"]
+                continue
+            if nd["mass"] > 0:
+                count += 1
+            no = nd["sibling"]
+        assert count == int(P["GravCost"][i])
     host.close()
 
 
