@@ -18,7 +18,7 @@ LIBGHIP = os.path.join(PKG_DIR, "libghip.so")
 LIBHOST = os.path.join(PKG_DIR, "libgadget_force.so")
 
 HIP_SOURCES = ["ghip_api.hip", "ghip_tree.hip", "ghip_gravity.hip", "ghip_sph.hip",
-               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip"]
+               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip", "ghip_pm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 
@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or _newer(LIBGHIP, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-o", LIBGHIP]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lhipfft", "-o", LIBGHIP]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

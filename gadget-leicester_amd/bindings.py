@@ -13,7 +13,7 @@ _pkg = importlib.import_module(__package__)
 # enum ghip_field
 (F_POS, F_VEL, F_MASS, F_TYPE, F_OLDACC, F_HSML, F_TIMEBIN, F_TI_BEGSTEP, F_VELPRED, F_ENTROPY,
  F_DTENTROPY, F_GRAVACCEL, F_GRAVCOST, F_NUMNGB, F_DENSITY, F_DHSMLFAC, F_DIVVEL, F_CURLVEL,
- F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_TI_CURRENT, F_COUNT) = range(23)
+ F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_TI_CURRENT, F_GRAVPM, F_COUNT) = range(24)
 
 _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_POS: (0, 3, 0), F_VEL: (0, 3, 0), F_MASS: (0, 1, 0), F_TYPE: (0, 1, 1), F_OLDACC: (0, 1, 0),
@@ -21,7 +21,7 @@ _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_ENTROPY: (1, 1, 0), F_DTENTROPY: (1, 1, 0), F_GRAVACCEL: (0, 3, 0), F_GRAVCOST: (0, 1, 1),
     F_NUMNGB: (1, 1, 0), F_DENSITY: (1, 1, 0), F_DHSMLFAC: (1, 1, 0), F_DIVVEL: (1, 1, 0),
     F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0),
-    F_TI_CURRENT: (0, 1, 1)}
+    F_TI_CURRENT: (0, 1, 1), F_GRAVPM: (0, 3, 0)}
 
 WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD = 0, 1, 2
 EN = 64
@@ -78,6 +78,11 @@ class KickParams(C.Structure):
                 ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p)]
 
 
+class PmParams(C.Structure):
+    _fields_ = [("pmgrid", C.c_int), ("BoxSize", C.c_double), ("G", C.c_double),
+                ("Asmth", C.c_double)]
+
+
 class NodeLayout(C.Structure):
     """ghip_node_layout: byte offsets of struct NODE / struct extNODE (allvars.h:1847-1916)"""
     _fields_ = [(k, C.c_int) for k in
@@ -105,7 +110,7 @@ class Stats(C.Structure):
                 ("ms_tree", C.c_float), ("ms_grav", C.c_float), ("ms_ewald", C.c_float),
                 ("ms_dens", C.c_float), ("ms_hmax", C.c_float), ("ms_hydro", C.c_float),
                 ("grav_wave_steps", C.c_longlong), ("ewald_wave_steps", C.c_longlong),
-                ("ms_kick", C.c_float)]
+                ("ms_kick", C.c_float), ("ms_pm", C.c_float)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -129,7 +134,7 @@ EXPORTS = [
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
-    "ghip_tree_export"]
+    "ghip_tree_export", "ghip_pm_periodic"]
 
 
 def lib():
@@ -177,6 +182,7 @@ def lib():
         L.ghip_timestep_endrun_code.argtypes = [vp]
         L.ghip_velocity_moments.argtypes = [vp, vp, vp, vp]
         L.ghip_download_aos_kick.argtypes = [vp, vp, vp, C.POINTER(Layout)]
+        L.ghip_pm_periodic.argtypes = [vp, C.POINTER(PmParams)]
         L.ghip_tree_export.argtypes = [vp, C.POINTER(NodeLayout), C.c_int, C.c_int, C.c_int, vp, vp,
                                        vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -357,6 +363,12 @@ class ForcePath:
                                           int(unequal), _ptr(nodes), _ptr(ext), _ptr(nxt), _ptr(fat),
                                           max_nodes, C.byref(nn)))
         return nodes[:nn.value], ext[:nn.value], nxt, fat
+
+    def pm_periodic(self, pmgrid, boxsize, G, asmth=None):
+        """ghip_pm_periodic: fills F_GRAVPM; asmth defaults to ASMTH * BoxSize / PMGRID."""
+        p = PmParams(int(pmgrid), float(boxsize), float(G),
+                     float(1.25 * boxsize / pmgrid if asmth is None else asmth))
+        self._chk(self.L.ghip_pm_periodic(self.h, C.byref(p)))
 
     def velocity_moments(self):
         v2 = (C.c_double * 6)()

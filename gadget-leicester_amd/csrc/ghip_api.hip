@@ -127,6 +127,10 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     free_buf(*b);
   free_tree(ctx->gt);
   free_tree(ctx->st);
+  ghip_pm_release(ctx);
+  free_buf(ctx->pm_rho);
+  free_buf(ctx->pm_k);
+  free_buf(ctx->pm_force);
   if(ctx->pinned)
     (void) hipHostFree(ctx->pinned);
   if(ctx->ev_ready)
@@ -173,7 +177,7 @@ static const FieldInfo kField[GHIP_F_COUNT] = {
   /* GRAVCOST */ {0, 1, 1},   /* NUMNGB */ {1, 1, 0},    /* DENSITY */ {1, 1, 0},
   /* DHSMLFAC */ {1, 1, 0},   /* DIVVEL */ {1, 1, 0},    /* CURLVEL */ {1, 1, 0},
   /* PRESSURE */ {1, 1, 0},   /* HYDROACCEL */ {1, 3, 0}, /* MAXSIGNALVEL */ {1, 1, 0},
-  /* TI_CURRENT */ {0, 1, 1}};
+  /* TI_CURRENT */ {0, 1, 1}, /* GRAVPM */ {0, 3, 0}};
 
 static size_t field_count(const ghip_ctx *ctx, int f)
 {
@@ -621,6 +625,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   S.ms_hmax = el(8, 9);
   S.ms_hydro = el(10, 11);
   S.ms_kick = el(12, 13);
+  S.ms_pm = el(14, 15);
   *out = S;
   return GHIP_OK;
 }

@@ -97,6 +97,10 @@ struct ghip_ctx
 
   // scan/sort temp
   DevBuf cubtmp;
+  // particle-mesh force (ghip_pm.hip): hipFFT plans for pm_n^3, mesh buffers
+  int pm_n = 0;
+  void *pm_fwd = nullptr, *pm_inv = nullptr;
+  DevBuf pm_rho, pm_k, pm_force;
   // counters (device): 8 x u64
   DevBuf counters;
   ghip_stats stats;
@@ -106,6 +110,7 @@ struct ghip_ctx
 };
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
+void ghip_pm_release(ghip_ctx *ctx);
 
 #define HIPCHK(call)                                                                         \
   do                                                                                         \

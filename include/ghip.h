@@ -67,6 +67,7 @@ enum ghip_field
   GHIP_F_HYDROACCEL,     /* SphP[].a.HydroAccel [ngas][3] f64 out */
   GHIP_F_MAXSIGNALVEL,   /* SphP[].MaxSignalVel [ngas] f64 out */
   GHIP_F_TI_CURRENT,     /* P[].Ti_current    [n]    i32 in/out (ghip_drift) */
+  GHIP_F_GRAVPM,         /* P[].GravPM        [n][3] f64 out (ghip_pm_periodic; PMGRID builds) */
   GHIP_F_COUNT
 };
 
@@ -163,6 +164,15 @@ typedef struct
   int ext_stride, e_dp, e_vs, e_vmax, e_divvmax, e_hmax, e_ti_lastkicked, e_flag;
 } ghip_node_layout;
 
+/* "next" row N3: periodic particle-mesh long-range force (pmforce_periodic, pm_periodic.c:199) */
+typedef struct
+{
+  int pmgrid;        /* PMGRID (even) */
+  double BoxSize;
+  double G;          /* All.G: GravPM comes out with G applied, as in the reference (:224) */
+  double Asmth;      /* All.Asmth[0] = ASMTH * BoxSize / PMGRID (pm_periodic.c:83) */
+} ghip_pm_params;
+
 /* work counters of the last phase, counted exactly as the reference counts them
  * (SURVEY.md 8d): used for roofline.achieved */
 typedef struct
@@ -181,6 +191,7 @@ typedef struct
   /* walk efficiency: elements visited summed over wavefronts (64 targets share each visit) */
   long long grav_wave_steps, ewald_wave_steps;
   float ms_kick;                 /* k_advance_timesteps of the last ghip_advance_timesteps */
+  float ms_pm;                   /* the last ghip_pm_periodic (deposit .. interpolation) */
 } ghip_stats;
 
 /* ---- lifetime ---- */
@@ -248,6 +259,11 @@ int ghip_download_aos_kick(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout
 int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int MaxPart, int Ti_Current,
                      int unequal_softenings, void *Nodes_base, void *Extnodes_base, int *Nextnode,
                      int *Father, int max_nodes, int *numnodes);
+
+/* ---- "next" row N3: P[].GravPM = long-range force of all particles on a PMGRID^3 periodic mesh
+ * (replaces long_range_force() -> pmforce_periodic(), longrange.c / pm_periodic.c:199-800; the
+ * field is zeroed first as long_range_force does).  Pairs with GHIP_WALK_SHORTRANGE. ---- */
+int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p);
 
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],

@@ -395,3 +395,57 @@ def set_num_threads(n):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def pm_periodic(pos, mass, boxsize, G, pmgrid, asmth=None):
+    """pmforce_periodic (pm_periodic.c:199-800) restated with numpy: CIC assignment (:226-330),
+    unnormalised forward FFT, Green's function with CIC deconvolution (:430-486), unnormalised
+    inverse FFT, 4-point differences (:489-560), CIC interpolation (:640-690).  Returns GravPM
+    [n][3] (G applied, as the reference).  The slab_z clamp typo of :263-264 is not reproduced."""
+    N = int(pmgrid)
+    pos = _f64(pos)
+    mass = _f64(mass)
+    asmth = 1.25 * boxsize / N if asmth is None else asmth     # ASMTH * BoxSize / PMGRID (:83)
+    to_slab = N / boxsize
+    sp = to_slab * pos
+    s = sp.astype(np.int64)                                     # (int) truncation
+    d = sp - s
+    s = np.minimum(s, N - 1)
+    rho = np.zeros((N, N, N))
+    corners = [(xx, yy, zz) for xx in (0, 1) for yy in (0, 1) for zz in (0, 1)]
+    w = {}
+    for (xx, yy, zz) in corners:
+        w[(xx, yy, zz)] = ((d[:, 0] if xx else 1.0 - d[:, 0]) * (d[:, 1] if yy else 1.0 - d[:, 1]) *
+                           (d[:, 2] if zz else 1.0 - d[:, 2]))
+        g = ((s[:, 0] + xx) % N, (s[:, 1] + yy) % N, (s[:, 2] + zz) % N)
+        np.add.at(rho, g, mass * w[(xx, yy, zz)])
+    fk = np.fft.rfftn(rho)                                      # unnormalised like FFTW
+    k1 = np.arange(N)
+    k1 = np.where(k1 > N // 2, k1 - N, k1).astype(np.float64)
+    kz1 = np.arange(N // 2 + 1, dtype=np.float64)
+    kx, ky, kz = np.meshgrid(k1, k1, kz1, indexing="ij")
+    k2 = kx * kx + ky * ky + kz * kz
+    asmth2 = ((2 * np.pi) * asmth / boxsize) ** 2
+
+    def sinc(k):
+        a = (np.pi * k) / N
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(k != 0, np.sin(a) / a, 1.0)
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        smth = -np.exp(-k2 * asmth2) / k2
+    ff = 1.0 / (sinc(kx) * sinc(ky) * sinc(kz))
+    smth = smth * ff * ff * ff * ff
+    smth[0, 0, 0] = 0.0
+    phi = np.fft.irfftn(fk * smth, s=(N, N, N), axes=(0, 1, 2)) * float(N) ** 3  # unnormalised inverse
+    fac = G / (np.pi * boxsize) * (1 / (2 * boxsize / N))
+    out = np.zeros((len(pos), 3))
+    for dim in range(3):
+        f = fac * ((4.0 / 3) * (np.roll(phi, 1, dim) - np.roll(phi, -1, dim)) -
+                   (1.0 / 6) * (np.roll(phi, 2, dim) - np.roll(phi, -2, dim)))
+        acc = np.zeros(len(pos))
+        for (xx, yy, zz) in corners:
+            g = ((s[:, 0] + xx) % N, (s[:, 1] + yy) % N, (s[:, 2] + zz) % N)
+            acc += f[g] * w[(xx, yy, zz)]
+        out[:, dim] = acc
+    return out

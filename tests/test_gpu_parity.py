@@ -1135,3 +1135,37 @@ def test_config_c5_size_256cubed_one_step_sampled():
     T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
     assert np.array_equal(cost[sample], ocost)
     assert relerr(acc[sample], oacc) < TOL
+
+
+@pytest.mark.parametrize("ng,pmgrid", [(16, 32), (32, 128)])
+def test_pm_periodic_long_range_force_parity(ng, pmgrid):
+    """"next" row N3: pmforce_periodic on the device (CIC, hipFFT, Green's function, 4-point
+    gradient, CIC) against the numpy restatement; FFT round-off only.  Then the TreePM sum of the
+    configuration c3 -- short-range tree walk + mesh force -- against direct Ewald summation."""
+    B = bindings()
+    pr = Problem(ng=ng, gas=True, periodic=1)
+    n = pr.n
+    G = 43007.1
+    fp = pr.device()
+    fp.pm_periodic(pmgrid, pr.box, G)
+    got = fp.get_field(B.F_GRAVPM)
+    want = O.pm_periodic(pr.ic["pos"], pr.ic["mass"], pr.box, G, pmgrid)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 1e-11 * scale
+    assert fp.stats()["ms_pm"] > 0
+    # total momentum of the mesh force vanishes (antisymmetric Green's function)
+    m = pr.ic["mass"]
+    assert np.abs((m[:, None] * got).sum(axis=0)).max() < 1e-9 * np.abs(m[:, None] * got).sum()
+    if pmgrid == 128:
+        # TreePM = short-range walk + PM: within the force-split / opening error of the exact
+        # periodic force (direct sum + Ewald correction) on a sample
+        asmth = 1.25 * pr.box / pmgrid
+        pr.device_tree(fp)
+        fp.set_field(B.F_OLDACC, np.zeros(n))
+        fp.gravity(pr.g_grav(0.3, 4.5 * asmth, asmth), B.WALK_SHORTRANGE)
+        total = G * fp.get_field(B.F_GRAVACCEL) + got
+        sample = np.sort(np.random.default_rng(1).choice(n, 128, replace=False)).astype(np.int32)
+        d = G * O.gravity_direct(pr.ic["pos"], m, pr.ic["type"], pr.force_soft, sample, periodic=1,
+                                 boxsize=pr.box, ewald_tab=O.ewald_table(pr.box))
+        err = np.linalg.norm(total[sample] - d, axis=1) / np.linalg.norm(d, axis=1)
+        assert np.median(err) < 0.01 and np.percentile(err, 95) < 0.05

@@ -333,3 +333,31 @@ def test_timestep_and_kick_restatement_against_hand_evaluation():
     P.MinSizeTimestep = 1.0
     assert O.advance_timesteps(P, ptype, vel, grav, hyd, vel[:ng].copy(), entropy, dtentropy,
                                np.ones(ng), np.ones(ng), hs, vsig, timebin, tbeg)["rc"] == 888
+
+
+def test_pm_restatement_long_range_force_of_a_point_mass():
+    """oracle.pm_periodic (pm_periodic.c:199-800) pinned by the analytic long-range part of the
+    TreePM force split: a point mass m attracts a test particle at distance r << L with
+    G m / r^2 * [erf(r / 2 r_s) - r / (r_s sqrt(pi)) exp(-r^2 / 4 r_s^2)]  (r_s = Asmth), up to the
+    periodic images and the mesh anisotropy."""
+    from math import erf, exp, pi, sqrt
+    box, N, G, m = 1.0, 64, 43007.1, 2.5
+    rs = 1.25 * box / N
+    src = np.array([0.5 + 0.3 / N, 0.5 + 0.1 / N, 0.5 + 0.7 / N])
+    rng = np.random.default_rng(4)
+    errs = []
+    for r in (3 * rs, 5 * rs, 8 * rs):
+        u = rng.standard_normal(3)
+        u /= np.linalg.norm(u)
+        pos = np.vstack([src, src + r * u])
+        acc = O.pm_periodic(pos, np.array([m, 0.0]), box, G, N)[1]       # massless test particle
+        want = -G * m / r ** 2 * (erf(r / (2 * rs)) - r / (rs * sqrt(pi)) * exp(-r * r / (4 * rs * rs)))
+        along = float(acc @ u)
+        across = np.linalg.norm(acc - along * u)
+        errs.append(abs(along - want) / abs(want))
+        assert across < 0.03 * abs(want)
+    assert max(errs) < 0.03
+    # momentum: the mesh force on two massive particles is equal and opposite
+    pos = np.vstack([src, src + 4 * rs * np.array([0.6, 0.0, 0.8])])
+    a = O.pm_periodic(pos, np.array([m, 3 * m]), box, G, N)
+    assert np.abs(m * a[0] + 3 * m * a[1]).max() < 1e-9 * np.abs(m * a[0]).max()
