@@ -147,6 +147,14 @@ void gadget_force_finalize(void)
   NgblistCap = 0;
   DeviceFresh = 0;
   TreeOnDevice = 0;
+  /* the host's arrays are the host's: forget them, a later init must set them again */
+  Nodes_base = Nodes = NULL;
+  Extnodes_base = Extnodes = NULL;
+  Nextnode = Father = NULL;
+  MaxNodes = Numnodestree = 0;
+  NextInTimeBin = PrevInTimeBin = NULL;
+  KickTabGrav = KickTabHydro = NULL;
+  dt_displacement = 0;
 }
 
 void gadget_force_layout(ghip_layout *lay)
