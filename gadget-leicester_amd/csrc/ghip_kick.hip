@@ -342,7 +342,7 @@ __global__ void k_vel_moments(int n, const int *__restrict__ type, const double 
       sm[threadIdx.x] = (ty == t) ? m : 1.0e30;
       sc[threadIdx.x] = (ty == t) ? 1u : 0u;
       __syncthreads();
-      for(int s = 128; s > 0; s >>= 1)
+      for(unsigned int s = 128; s > 0; s >>= 1)
         {
           if(threadIdx.x < s)
             {

@@ -598,7 +598,6 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
                      target);
   hipStream_t st = ctx->stream;
   TreeDev &t = ctx->st;
-  int ng = ctx->ngas;
   GCHK(dens_alloc(ctx));
   double *hcur = P<double>(ctx->dhcur);
   const int nsub = 1;
