@@ -289,7 +289,19 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
           int e = base + (L - cprev - 1);
           int sh = 63 - 3 * L;
           unsigned long long prefix = ki >> sh;
+          // end of the cell's particle range: gallop, then bisect (most cells hold a handful of
+          // particles, so the doubling phase ends after two or three probes)
           int lo = i + 1, hi = n;
+          for(int step = 1; lo + step < n; step <<= 1)
+            {
+              if((skey[lo + step] >> sh) == prefix)
+                lo = lo + step + 1;
+              else
+                {
+                  hi = lo + step;
+                  break;
+                }
+            }
           while(lo < hi)
             {
               int mid = (lo + hi) >> 1;
