@@ -263,21 +263,35 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
       if(v >= 1 && v <= 4096)
         ns = v;
     }
-  // a second, 4x coarser table for the Ewald walk: it visits ~6x fewer elements per bucket, so
-  // the ancestor replays of a fine table would be a third of its work
-  int ns2 = ns / 4;
-  if(ns2 < 1)
-    ns2 = 1;
+  // three tables: fine (ns), mid (ns/2), coarse (ns/4).  The fine one serves small launches (one
+  // rank's share of a multi-GPU run: many wavefronts per bucket), the mid one a full-size
+  // Newtonian walk (enough buckets to fill the chip, so fewer ancestor replays win: 7.0 -> 6.8 ms
+  // at c2), the coarse one the Ewald walk, which visits ~6x fewer elements per bucket.
+  SegTables T;
+  T.ntab = 3;
+  int so = 0, no = 0, total = 0;
+  for(int j = 0; j < 3; j++)
+    {
+      int v = ns >> j;
+      T.ns[j] = v < 1 ? 1 : v;
+      T.soff[j] = so;
+      T.noff[j] = no;
+      so += T.ns[j] + 1;
+      no += T.ns[j];
+      total += T.ns[j] + 1;
+    }
   t.ns = ns;
-  t.ns2 = ns2;
-  GCHK(ghip_ensure(ctx, t.seg_start, (size_t) (ns + 1 + ns2 + 1) * 4));
-  GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) (ns + ns2) * 4));
-  GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) (ns + ns2) * GHIP_MAXANC * 4));
-  k_build_segments<<<cdiv(ns + 1, 64), 64, 0, ctx->stream>>>(
-    t.nelem, P<int4>(t.lk), ns, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
-  k_build_segments<<<cdiv(ns2 + 1, 64), 64, 0, ctx->stream>>>(
-    t.nelem, P<int4>(t.lk), ns2, P<int>(t.seg_start) + ns + 1, P<int>(t.seg_nanc) + ns,
-    P<int>(t.seg_anc) + (size_t) ns * GHIP_MAXANC);
+  for(int j = 0; j < 3; j++)
+    {
+      t.seg_ns[j] = T.ns[j];
+      t.seg_soff[j] = T.soff[j];
+      t.seg_noff[j] = T.noff[j];
+    }
+  GCHK(ghip_ensure(ctx, t.seg_start, (size_t) so * 4));
+  GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) no * 4));
+  GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) no * GHIP_MAXANC * 4));
+  k_build_segments<<<cdiv(total, 64), 64, 0, ctx->stream>>>(
+    t.nelem, P<int4>(t.lk), T, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
   HIPCHK(hipGetLastError());
   if(!walk_records)
     return GHIP_OK;
@@ -291,9 +305,10 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   return GHIP_OK;
 }
 
-int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, bool coarse)
+// table 0 fine, 1 mid, 2 coarse (ghip_build_segments)
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, int table)
 {
-  sg.ns = coarse ? t.ns2 : t.ns;
+  sg.ns = t.seg_ns[table];
   sg.nsub = sg.ns < GHIP_MAXSUB ? sg.ns : GHIP_MAXSUB;
   if(getenv("GHIP_WALK_SUBS"))
     {
@@ -303,16 +318,24 @@ int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, bool coarse)
     }
   if(sg.nsub < 1)
     sg.nsub = 1;
-  sg.start = P<int>(t.seg_start) + (coarse ? t.ns + 1 : 0);
-  sg.nanc = P<int>(t.seg_nanc) + (coarse ? t.ns : 0);
-  sg.anc = P<int>(t.seg_anc) + (coarse ? (size_t) t.ns * GHIP_MAXANC : 0);
+  sg.start = P<int>(t.seg_start) + t.seg_soff[table];
+  sg.nanc = P<int>(t.seg_nanc) + t.seg_noff[table];
+  sg.anc = P<int>(t.seg_anc) + (size_t) t.seg_noff[table] * GHIP_MAXANC;
   return sg.nsub;
 }
 
-static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, bool coarse)
+static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, bool ewald)
 {
   *nbuckets = (nt + 63) / 64;
-  return ghip_walk_layout(t, sg, coarse);
+  static int mid_min = -1;
+  if(mid_min < 0)
+    {
+      mid_min = 6144;   // buckets from which a Newtonian walk uses the mid table
+      if(getenv("GHIP_WALK_MID_MIN"))
+        mid_min = atoi(getenv("GHIP_WALK_MID_MIN"));
+    }
+  int table = ewald ? 2 : (*nbuckets >= mid_min ? 1 : 0);
+  return ghip_walk_layout(t, sg, table);
 }
 
 static int ensure_partials(ghip_ctx *ctx, int nwaves)

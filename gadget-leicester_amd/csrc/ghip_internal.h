@@ -40,7 +40,8 @@ struct TreeDev
   DevBuf xm, cl, lk, aux;              // double4[nelem], double4[nelem], int4[nelem], f64[nelem]
   // walk segments (ghip_walk.h): start[ns+1], nanc[ns], anc[ns][GHIP_MAXANC]
   DevBuf seg_start, seg_nanc, seg_anc;
-  int ns = 1, ns2 = 1;   // fine table (Newton / short-range walk), coarse table (Ewald walk)
+  int ns = 1;            // segments of the fine table
+  int seg_ns[3] = {1, 1, 1}, seg_soff[3] = {0, 0, 0}, seg_noff[3] = {0, 0, 0};   // fine / mid / coarse
   DevBuf mq, mq2;                      // WalkHot[nelem], WalkCold[nelem]: walk records (gravity tree)
   bool built = false;
 };
@@ -194,7 +195,7 @@ struct WalkSeg
   const int *__restrict__ anc;     // [ns][GHIP_MAXANC] ancestors of start[k], root first
 };
 
-int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, bool coarse);   // returns nsub
+int ghip_walk_layout(const TreeDev &t, WalkSeg &sg, int table);   // returns nsub
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -709,15 +709,33 @@ __global__ void k_plan_fill(int nb, const int *__restrict__ nsub, const int *__r
   steps_out[b] = 0;
 }
 
-// segment table of a tree: equal-length slices of the element list + the ancestor chain of each
-// slice's first element (one thread per segment; a pre-order descent from the root)
-__global__ void k_build_segments(int nelem, const int4 *__restrict__ lk, int ns,
+// segment tables of a tree: equal-length slices of the element list + the ancestor chain of each
+// slice's first element (one thread per segment; a pre-order descent from the root).  Up to three
+// tables of different granularity are built by one launch; table j has ns[j] segments and lives at
+// start + soff[j] (ns[j] + 1 entries), nanc + noff[j], anc + noff[j] * GHIP_MAXANC.
+struct SegTables
+{
+  int ntab;
+  int ns[3], soff[3], noff[3];
+};
+
+__global__ void k_build_segments(int nelem, const int4 *__restrict__ lk, SegTables T,
                                  int *__restrict__ start, int *__restrict__ nanc,
                                  int *__restrict__ anc)
 {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if(k > ns)
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = 0;
+  while(j < T.ntab && g > T.ns[j])
+    {
+      g -= T.ns[j] + 1;
+      j++;
+    }
+  if(j >= T.ntab)
     return;
+  const int ns = T.ns[j], k = g;
+  start += T.soff[j];
+  nanc += T.noff[j];
+  anc += (size_t) T.noff[j] * GHIP_MAXANC;
   long long chunk = ((long long) nelem + ns - 1) / ns;
   long long s0l = (long long) k * chunk;
   int s0 = (int) (s0l > nelem ? nelem : s0l);
