@@ -444,6 +444,14 @@ def test_tiny_and_ragged_inputs(n, ngas):
         fp.density(B.DensParams(33, 2, 0, 1, 0, 0, 0, 150))
         fp.hydro(B.HydroParams(0.8, 1, 0, 0, 1, 1, 1, 0, 0))
         assert fp.stats()["grav_interactions"] == 0
+        # the "next" rows on an empty particle set
+        fp.pm_periodic(16, 1.0, 1.0)
+        nodes, ext, nxt, fat = fp.tree_export(maxpart=4)
+        assert len(nodes) == 0 and np.all(nxt == -1)
+        kp = _fill(B.KickParams(), _kick_case(Problem(ng=4, gas=True), False)[1], np.full(6, 0.01))
+        cnt, sph = fp.advance_timesteps(kp)
+        assert cnt.sum() == 0 and sph.sum() == 0
+        assert fp.velocity_moments()[2].sum() == 0
         return
     pr = Problem(ic=ic, periodic=0, des_ngb=min(33.0, max(ngas - 1, 1)))
     if ngas:
@@ -455,6 +463,26 @@ def test_tiny_and_ragged_inputs(n, ngas):
     oacc, ocost = T.gravity(pr.o_grav(0.5), _all(n), np.zeros(n))
     assert np.array_equal(fp.get_field(B.F_GRAVCOST), ocost)
     assert np.abs(fp.get_field(B.F_GRAVACCEL) - oacc).max() <= TOL * max(np.abs(oacc).max(), 1e-300)
+    # the "next" rows on tiny inputs: exported links thread every particle, the mesh force is
+    # finite, the kick handles an empty active list
+    nodes, ext, nxt, fat = fp.tree_export(maxpart=n)
+    assert len(nodes) == T.numnodes
+    seen, no = 0, (n if len(nodes) else 0)
+    while no >= 0 and seen <= n:
+        if no < n:
+            seen += 1
+            no = nxt[no]
+        else:
+            no = nodes["nextnode"][no - n]
+    assert seen == n
+    fp.pm_periodic(16, 1.0, 1.0)
+    assert np.isfinite(fp.get_field(B.F_GRAVPM)).all()
+    fp.set_active(np.zeros(0, np.int32))
+    kp = _fill(B.KickParams(), _kick_case(Problem(ng=4, gas=True), False)[1], pr.force_soft / 2.8)
+    v0 = fp.get_field(B.F_VEL)
+    cnt, _sph = fp.advance_timesteps(kp)
+    assert cnt.sum() == n and np.array_equal(fp.get_field(B.F_VEL), v0)
+    fp.set_active(None)
     if ngas >= 40:
         od, oh = _oracle_sph(pr, T, _all(ngas))
         fp.density(pr.g_dens())
