@@ -75,6 +75,59 @@ __device__ __forceinline__ double d_wrap(double d, const BoxK b)
   return d;
 }
 
+// Bounds of a bucket's targets around the first target: half extents per axis (nearest-image
+// offsets) and the largest search radius.  A staged candidate can be a neighbour of SOME lane only
+// if |wrap(x_j - c)| <= extent + radius on every axis (triangle inequality of the periodic
+// distance), so the lane that stages candidate j tests it once against the bucket, and the 64-lane
+// loop runs over the survivors only -- typically 60 % of a leaf's particles.
+struct BucketBox
+{
+  double cx, cy, cz, ex, ey, ez, hmax;
+};
+
+__device__ __forceinline__ double d_wave_max_f64(double v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      double o = __shfl_xor(v, off, 64);
+      v = o > v ? o : v;
+    }
+  return v;
+}
+
+__device__ __forceinline__ double d_first_lane_f64(double v)
+{
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ BucketBox d_bucket_box(bool valid, double px, double py, double pz,
+                                                  double h, const BoxK b)
+{
+  BucketBox B;
+  B.cx = d_first_lane_f64(px);   // lane 0 of a bucket always holds a target
+  B.cy = d_first_lane_f64(py);
+  B.cz = d_first_lane_f64(pz);
+  B.ex = d_wave_max_f64(valid ? fabs(d_wrap(px - B.cx, b)) : 0.0);
+  B.ey = d_wave_max_f64(valid ? fabs(d_wrap(py - B.cy, b)) : 0.0);
+  B.ez = d_wave_max_f64(valid ? fabs(d_wrap(pz - B.cz, b)) : 0.0);
+  B.hmax = d_wave_max_f64(valid ? h : 0.0);
+  return B;
+}
+
+// mask of the staged candidates (lane l holds candidate l) that can be within max(hmax, hj) of
+// any target of the bucket
+__device__ __forceinline__ unsigned long long d_cull_batch(const BucketBox &B, bool staged, double jx,
+                                                            double jy, double jz, double hj,
+                                                            const BoxK b)
+{
+  const double H = B.hmax > hj ? B.hmax : hj;
+  bool pass = staged && fabs(d_wrap(jx - B.cx, b)) <= B.ex + H &&
+              fabs(d_wrap(jy - B.cy, b)) <= B.ey + H && fabs(d_wrap(jz - B.cz, b)) <= B.ez + H;
+  return __builtin_amdgcn_ballot_w64(pass);
+}
+
 // ---------------------------------------------------------------------------------------------
 // density
 // ---------------------------------------------------------------------------------------------
@@ -152,6 +205,7 @@ __device__ __forceinline__ void d_load_sphnode(const SphNode *__restrict__ base,
 
 #define SPH_STAGE 64   // candidates staged through LDS per node (= lanes of the staging load)
 
+
 // density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 curve-consecutive targets.
 // One wavefront per workgroup.  Node records come through the scalar path; when a node with
 // <= 64 gas particles overlaps any lane's search sphere its particle records (contiguous in
@@ -188,6 +242,7 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
   const double h2 = h * h, hinv = 1.0 / h;
   const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv;
   DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
+  const BucketBox BB = d_bucket_box(valid, px, py, pz, h, b);
 
   int e = 0;
   while(e < nelem)
@@ -214,17 +269,25 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
                   if((batch++ % nsub) == sub)
                     {
                       __syncthreads();   // previous batch fully consumed
+                      double4 c0 = make_double4(0, 0, 0, 0);
                       if(lane < pcount)
                         {
                           const double4 *src =
                             reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
-                          sh[lane][0] = src[0];
+                          c0 = src[0];
+                          sh[lane][0] = c0;
                           sh[lane][1] = src[1];
                         }
+                      unsigned long long live =
+                        d_cull_batch(BB, lane < pcount, c0.x, c0.y, c0.z, 0.0, b);
                       __syncthreads();
-                      for(int j = 0; j < pcount; j++)
-                        d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px, py,
-                                       pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+                      while(live)
+                        {
+                          const int j = __builtin_ctzll(live);
+                          live &= live - 1;
+                          d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px, py,
+                                         pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+                        }
                     }
                   e = skip;
                 }
@@ -849,6 +912,7 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
       T.p_over_rho2_i *= dhf;
     }
   HydAcc A = {0, 0, 0, 0, 0, 0};
+  const BucketBox BB = d_bucket_box(valid, T.px, T.py, T.pz, T.h_i, b);
 
   int e = 0;
   while(e < nelem)
@@ -876,21 +940,31 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
                   if((batch++ % nsub) == sub)
                     {
                   __syncthreads();
+                  double4 c0 = make_double4(0, 0, 0, 0), c1 = make_double4(0, 0, 0, 0);
                   if(lane < pcount)
                     {
                       const double4 *s0 =
                         reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
                       const double4 *s1 =
                         reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + lane));
-                      sh[lane][0] = s0[0];
-                      sh[lane][1] = s0[1];
+                      c0 = s0[0];
+                      c1 = s0[1];
+                      sh[lane][0] = c0;
+                      sh[lane][1] = c1;
                       sh[lane][2] = s1[0];
                       sh[lane][3] = s1[1];
                     }
+                  // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
+                  unsigned long long live =
+                    d_cull_batch(BB, lane < pcount, c0.x, c0.y, c0.z, c1.w, b);
                   __syncthreads();
-                  for(int j = 0; j < pcount; j++)
-                    d_hydro_pair(reinterpret_cast<const double *>(&sh[j][0]),
-                                 reinterpret_cast<const double *>(&sh[j][2]), valid, T, K, b, A);
+                  while(live)
+                    {
+                      const int j = __builtin_ctzll(live);
+                      live &= live - 1;
+                      d_hydro_pair(reinterpret_cast<const double *>(&sh[j][0]),
+                                   reinterpret_cast<const double *>(&sh[j][2]), valid, T, K, b, A);
+                    }
                     }
                   e = skip;
                 }
