@@ -203,7 +203,10 @@ __device__ __forceinline__ void d_load_sphnode(const SphNode *__restrict__ base,
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(R) : "s"(p) : "memory");
 }
 
-#define SPH_STAGE 64   // candidates staged through LDS per node (= lanes of the staging load)
+#define SPH_STAGE 64   // candidates staged through LDS per round (= lanes of the staging load)
+#ifndef SPH_LEAF
+#define SPH_LEAF 256   // a node with at most this many particles is swept flat, SPH_STAGE at a time
+#endif
 
 
 // density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 curve-consecutive targets.
@@ -264,31 +267,32 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
           bool open = valid && d_node_overlaps(c, h, px, py, pz, b);
           if(__any(open))
             {
-              if(pcount <= SPH_STAGE)
+              if(pcount <= SPH_LEAF)
                 {
-                  if((batch++ % nsub) == sub)
-                    {
-                      __syncthreads();   // previous batch fully consumed
-                      double4 c0 = make_double4(0, 0, 0, 0);
-                      if(lane < pcount)
-                        {
-                          const double4 *src =
-                            reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
-                          c0 = src[0];
-                          sh[lane][0] = c0;
-                          sh[lane][1] = src[1];
-                        }
-                      unsigned long long live =
-                        d_cull_batch(BB, lane < pcount, c0.x, c0.y, c0.z, 0.0, b);
-                      __syncthreads();
-                      while(live)
-                        {
-                          const int j = __builtin_ctzll(live);
-                          live &= live - 1;
-                          d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px, py,
-                                         pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
-                        }
-                    }
+                  for(int r0 = 0; r0 < pcount; r0 += SPH_STAGE)
+                    if((batch++ % nsub) == sub)
+                      {
+                        const bool staged = r0 + lane < pcount;
+                        __syncthreads();   // previous round fully consumed
+                        double4 c0 = make_double4(0, 0, 0, 0);
+                        if(staged)
+                          {
+                            const double4 *src = reinterpret_cast<const double4 *>(
+                              gp + (size_t) 8 * (pstart + r0 + lane));
+                            c0 = src[0];
+                            sh[lane][0] = c0;
+                            sh[lane][1] = src[1];
+                          }
+                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, 0.0, b);
+                        __syncthreads();
+                        while(live)
+                          {
+                            const int j = __builtin_ctzll(live);
+                            live &= live - 1;
+                            d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px,
+                                           py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+                          }
+                      }
                   e = skip;
                 }
               else
@@ -935,18 +939,20 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
           bool open = valid && d_node_overlaps(c, dist, T.px, T.py, T.pz, b);
           if(__any(open))
             {
-              if(pcount <= SPH_STAGE)
+              if(pcount <= SPH_LEAF)
                 {
+                  for(int r0 = 0; r0 < pcount; r0 += SPH_STAGE)
                   if((batch++ % nsub) == sub)
                     {
+                  const bool staged = r0 + lane < pcount;
                   __syncthreads();
                   double4 c0 = make_double4(0, 0, 0, 0), c1 = make_double4(0, 0, 0, 0);
-                  if(lane < pcount)
+                  if(staged)
                     {
                       const double4 *s0 =
-                        reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + lane));
+                        reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + r0 + lane));
                       const double4 *s1 =
-                        reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + lane));
+                        reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + r0 + lane));
                       c0 = s0[0];
                       c1 = s0[1];
                       sh[lane][0] = c0;
@@ -956,7 +962,7 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
                     }
                   // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
                   unsigned long long live =
-                    d_cull_batch(BB, lane < pcount, c0.x, c0.y, c0.z, c1.w, b);
+                    d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c1.w, b);
                   __syncthreads();
                   while(live)
                     {
