@@ -23,7 +23,7 @@ _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0),
     F_TI_CURRENT: (0, 1, 1), F_GRAVPM: (0, 3, 0)}
 
-WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD = 0, 1, 2
+WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD, WALK_NEWTON_EWALD = 0, 1, 2, 3
 EN = 64
 
 GHIP_ERRORS = {-90001: "GHIP_EHIP", -90002: "GHIP_EINVAL", -90003: "GHIP_ENOMEM",
@@ -220,6 +220,9 @@ class ForcePath:
             self.close()
         except Exception:
             pass
+
+    # walk constant of the overlapped Newton+Ewald pair (sharded.py uses it when present)
+    WALK_PAIR = (WALK_NEWTON, WALK_EWALD, WALK_NEWTON_EWALD)
 
     def _chk(self, rc):
         if rc != 0:

@@ -81,6 +81,18 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         return GHIP_EHIP;
       }
   ctx->ev_ready = true;
+  if(hipStreamCreate(&ctx->stream2) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_EHIP;
+    }
+  for(int i = 0; i < 3; i++)
+    if(hipEventCreateWithFlags(&ctx->evx[i], hipEventDisableTiming) != hipSuccess)
+      {
+        delete ctx;
+        return GHIP_EHIP;
+      }
+  ctx->evx_ready = true;
   // device counters start at zero (hipMalloc does not clear)
   if(ghip_ensure(ctx, ctx->counters, 64 * 8) != GHIP_OK ||
      hipMemset(ctx->counters.p, 0, ctx->counters.cap) != hipSuccess)
@@ -111,6 +123,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   (void) hipSetDevice(ctx->device);
   if(ctx->stream)
     (void) hipStreamSynchronize(ctx->stream);
+  if(ctx->stream2)
+    (void) hipStreamSynchronize(ctx->stream2);
   for(int i = 0; i < GHIP_F_COUNT; i++)
     free_buf(ctx->f[i]);
   DevBuf *bs[] = {&ctx->stage,  &ctx->aosP,   &ctx->aosS,    &ctx->sx,      &ctx->sy,
@@ -122,7 +136,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
                   &ctx->counters, &ctx->dhcur, &ctx->hpart, &ctx->plan_nsub, &ctx->plan_woff,
                   &ctx->plan_wave, &ctx->plan_steps[0][0], &ctx->plan_steps[0][1],
                   &ctx->plan_steps[1][0], &ctx->plan_steps[1][1], &ctx->plan_steps[2][0],
-                  &ctx->plan_steps[2][1]};
+                  &ctx->plan_steps[2][1], &ctx->tax2, &ctx->tay2, &ctx->taz2, &ctx->tcost2,
+                  &ctx->plan_nsub2, &ctx->plan_woff2, &ctx->plan_wave2, &ctx->cubtmp2};
   for(DevBuf *b : bs)
     free_buf(*b);
   free_tree(ctx->gt);
@@ -136,6 +151,11 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(ctx->ev_ready)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
+  if(ctx->evx_ready)
+    for(int i = 0; i < 3; i++)
+      (void) hipEventDestroy(ctx->evx[i]);
+  if(ctx->stream2)
+    (void) hipStreamDestroy(ctx->stream2);
   if(ctx->stream)
     (void) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -338,21 +338,36 @@ static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, boo
   return ghip_walk_layout(t, sg, table);
 }
 
-static int ensure_partials(ghip_ctx *ctx, int nwaves)
+// per-wavefront partial results; slot 1 = second set (the Ewald walk of an overlapped pair)
+struct PartialBufs
+{
+  double *ax, *ay, *az;
+  int *cost;
+};
+
+static int ensure_partials(ghip_ctx *ctx, int nwaves, int slot, PartialBufs &pb)
 {
   size_t cnt = (size_t) nwaves * 64;
-  GCHK(ghip_ensure(ctx, ctx->tax, cnt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tay, cnt * 8));
-  GCHK(ghip_ensure(ctx, ctx->taz, cnt * 8));
-  GCHK(ghip_ensure(ctx, ctx->tcost, cnt * 4));
+  DevBuf &bx = slot ? ctx->tax2 : ctx->tax, &by = slot ? ctx->tay2 : ctx->tay,
+         &bz = slot ? ctx->taz2 : ctx->taz, &bc = slot ? ctx->tcost2 : ctx->tcost;
+  GCHK(ghip_ensure(ctx, bx, cnt * 8));
+  GCHK(ghip_ensure(ctx, by, cnt * 8));
+  GCHK(ghip_ensure(ctx, bz, cnt * 8));
+  GCHK(ghip_ensure(ctx, bc, cnt * 4));
+  pb.ax = P<double>(bx);
+  pb.ay = P<double>(by);
+  pb.az = P<double>(bz);
+  pb.cost = P<int>(bc);
   return GHIP_OK;
 }
 
 // wavefront plan of one walk call (see k_plan_nsub): kind 0 Newton/short-range, 1 Ewald,
 // 2 external targets (never has history)
-static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan)
+static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, int slot = 0)
 {
   hipStream_t st = ctx->stream;
+  DevBuf &b_nsub = slot ? ctx->plan_nsub2 : ctx->plan_nsub, &b_woff = slot ? ctx->plan_woff2 : ctx->plan_woff,
+         &b_wave = slot ? ctx->plan_wave2 : ctx->plan_wave, &b_tmp = slot ? ctx->cubtmp2 : ctx->cubtmp;
   int sbase = (49152 + nb - 1) / nb;
   sbase = sbase < 8 ? 8 : (sbase > 64 ? 64 : sbase);
   if(sbase > ns)
@@ -364,9 +379,9 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan)
         sbase = v;
     }
   const int maxwaves = (sbase + 2) * nb + 8;
-  GCHK(ghip_ensure(ctx, ctx->plan_nsub, (size_t) nb * 4));
-  GCHK(ghip_ensure(ctx, ctx->plan_woff, (size_t) (nb + 1) * 4));
-  GCHK(ghip_ensure(ctx, ctx->plan_wave, (size_t) maxwaves * 4));
+  GCHK(ghip_ensure(ctx, b_nsub, (size_t) nb * 4));
+  GCHK(ghip_ensure(ctx, b_woff, (size_t) (nb + 1) * 4));
+  GCHK(ghip_ensure(ctx, b_wave, (size_t) maxwaves * 4));
   GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][0], (size_t) nb * 4));
   GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][1], (size_t) nb * 4));
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
@@ -382,16 +397,16 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan)
     HIPCHK(hipMemcpyAsync(total_prev, P<unsigned long long>(ctx->counters) + 8 + kind, 8,
                           hipMemcpyDeviceToDevice, st));
   k_plan_nsub<<<cdiv(nb, 256), 256, 0, st>>>(nb, ns, sbase, prev, total_prev, have_prev,
-                                             P<int>(ctx->plan_nsub));
+                                             P<int>(b_nsub));
   size_t tb = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(ctx->plan_nsub),
-                                          P<int>(ctx->plan_woff), nb, st));
-  GCHK(ghip_ensure(ctx, ctx->cubtmp, tb + 256));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, P<int>(ctx->plan_nsub),
-                                          P<int>(ctx->plan_woff), nb, st));
-  HIPCHK(hipMemsetAsync(ctx->plan_wave.p, 0xff, (size_t) maxwaves * 4, st));
-  k_plan_fill<<<cdiv(nb, 256), 256, 0, st>>>(nb, P<int>(ctx->plan_nsub), P<int>(ctx->plan_woff),
-                                             maxwaves, P<int>(ctx->plan_wave), out);
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(b_nsub),
+                                          P<int>(b_woff), nb, st));
+  GCHK(ghip_ensure(ctx, b_tmp, tb + 256));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, P<int>(b_nsub),
+                                          P<int>(b_woff), nb, st));
+  HIPCHK(hipMemsetAsync(b_wave.p, 0xff, (size_t) maxwaves * 4, st));
+  k_plan_fill<<<cdiv(nb, 256), 256, 0, st>>>(nb, P<int>(b_nsub), P<int>(b_woff),
+                                             maxwaves, P<int>(b_wave), out);
   HIPCHK(hipGetLastError());
   if(kind < 2)
     {
@@ -400,9 +415,9 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan)
       ctx->plan_cur[kind] = cur ^ 1;
     }
   plan.nwaves = maxwaves;
-  plan.wave_bucket = P<int>(ctx->plan_wave);
-  plan.woff = P<int>(ctx->plan_woff);
-  plan.nsub = P<int>(ctx->plan_nsub);
+  plan.wave_bucket = P<int>(b_wave);
+  plan.woff = P<int>(b_woff);
+  plan.nsub = P<int>(b_nsub);
   plan.steps_out = out;
   return GHIP_OK;
 }
@@ -411,7 +426,8 @@ template <int MODE>
 static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int nbuckets, int nt,
                         const int *tgt, const double *tx, const double *ty, const double *tz,
                         const double *tsoft, const double *toldacc, const GravK &k,
-                        unsigned long long *counter, const WalkPlan &plan)
+                        unsigned long long *counter, const WalkPlan &plan, const PartialBufs &pb,
+                        hipStream_t stream)
 {
   (void) nbuckets;
   long long nthreads = (long long) plan.nwaves * 64;
@@ -427,10 +443,9 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
-  k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, 0, ctx->stream>>>(                                 \
+  k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, 0, stream>>>(                                      \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
-    P<float>(ctx->srtab), P<double>(ctx->ewtab), P<double>(ctx->tax), P<double>(ctx->tay),        \
-    P<double>(ctx->taz), P<int>(ctx->tcost), counter, plan)
+    P<float>(ctx->srtab), P<double>(ctx->ewtab), pb.ax, pb.ay, pb.az, pb.cost, counter, plan)
   // (the Ewald walk has no softening rule: one variant)
   const bool uneq = (MODE != GHIP_WALK_EWALD) && k.unequal;
   if(k.periodic && uneq)
@@ -448,17 +463,17 @@ static void launch_walk_any(ghip_ctx *ctx, int walk, const TreeDev &t, const Wal
                             int nbuckets, int nt, const int *tgt, const double *tx,
                             const double *ty, const double *tz, const double *tsoft,
                             const double *toldacc, const GravK &k, unsigned long long *counter,
-                            const WalkPlan &plan)
+                            const WalkPlan &plan, const PartialBufs &pb, hipStream_t stream)
 {
   if(walk == GHIP_WALK_NEWTON)
     launch_walk<GHIP_WALK_NEWTON>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                  counter, plan);
+                                  counter, plan, pb, stream);
   else if(walk == GHIP_WALK_SHORTRANGE)
     launch_walk<GHIP_WALK_SHORTRANGE>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                      counter, plan);
+                                      counter, plan, pb, stream);
   else
     launch_walk<GHIP_WALK_EWALD>(ctx, t, sg, nbuckets, nt, tgt, tx, ty, tz, tsoft, toldacc, k,
-                                 counter, plan);
+                                 counter, plan, pb, stream);
 }
 
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
@@ -467,23 +482,72 @@ static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
   ghip_shard_range(nt, ctx->shard_n, ctx->shard_rank, lo, cnt, &per);
 }
 
+// everything one walk launch needs; prepared on the main stream
+struct WalkJob
+{
+  int walk;
+  GravK k;
+  WalkSeg sg;
+  WalkPlan plan;
+  PartialBufs pb;
+  int nbuckets;
+  unsigned long long *counter;
+};
+
+static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt, int slot,
+                       WalkJob &J)
+{
+  J.walk = walk;
+  GCHK(prepare_tables(ctx, p, walk, J.k));
+  walk_layout(ctx->gt, nt, J.sg, &J.nbuckets, walk == GHIP_WALK_EWALD);
+  GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, J.nbuckets, J.sg.ns, J.plan, slot));
+  GCHK(ensure_partials(ctx, J.plan.nwaves, slot, J.pb));
+  J.counter = P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
+  HIPCHK(hipMemsetAsync(J.counter, 0, 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(J.counter + 8, 0, 8, ctx->stream));
+  return GHIP_OK;
+}
+
+static int run_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt, hipStream_t st)
+{
+  int evi = (J.walk == GHIP_WALK_EWALD) ? 4 : 2;
+  HIPCHK(hipEventRecord(ctx->ev[evi], st));
+  launch_walk_any(ctx, J.walk, ctx->gt, J.sg, J.nbuckets, nt, tgt, P<double>(ctx->sx),
+                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
+                  P<double>(ctx->soldacc), J.k, J.counter, J.plan, J.pb, st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[evi + 1], st));
+  return GHIP_OK;
+}
+
+static int combine_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt, hipStream_t st)
+{
+  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
+    nt, J.plan, tgt, P<int>(ctx->gt.perm), J.pb.ax, J.pb.ay, J.pb.az, J.pb.cost, ctx->n,
+    P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<int>(ctx->f[GHIP_F_GRAVCOST]),
+    J.walk == GHIP_WALK_EWALD ? 1 : 0, J.k.debug_steps);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 {
   if(!ctx->gt.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity: call ghip_tree_build first");
-  if(walk < 0 || walk > 2)
+  if(walk < 0 || walk > GHIP_WALK_NEWTON_EWALD)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity: unknown walk %d", walk);
-  GravK k;
-  GCHK(prepare_tables(ctx, p, walk, k));
+  const bool pair = (walk == GHIP_WALK_NEWTON_EWALD);
+  if(pair && !p->periodic)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity: the Newton+Ewald pair needs periodic = 1");
   GCHK(ghip_build_target_lists(ctx));
   hipStream_t st = ctx->stream;
   int n = ctx->n;
   int lo, nt;
   shard_slice(ctx, ctx->nt_grav, &lo, &nt);
   ghip_stats &S = ctx->stats;
-  if(walk == GHIP_WALK_EWALD)
+  if(walk == GHIP_WALK_EWALD || pair)
     S.ewald_interactions = 0;
-  else
+  if(walk != GHIP_WALK_EWALD)
     {
       S.grav_interactions = 0;
       S.grav_targets = nt;
@@ -491,34 +555,34 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   if(nt == 0 || n == 0)
     return GHIP_OK;
   const int *tgt = P<int>(ctx->tg_grav) + lo;
-  WalkSeg sg;
-  int nbuckets;
-  walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
-  WalkPlan plan;
-  GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, nbuckets, sg.ns, plan));
-  GCHK(ensure_partials(ctx, plan.nwaves));
-  unsigned long long *counter =
-    P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
-  HIPCHK(hipMemsetAsync(counter, 0, 8, st));
-  HIPCHK(hipMemsetAsync(counter + 8, 0, 8, st));
+  WalkJob A, E;
+  GCHK(prepare_job(ctx, p, pair ? GHIP_WALK_NEWTON : walk, nt, 0, A));
+  if(pair)
+    GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E));
 
   // OldAcc in tree order (forcetree.c:1850: aold = ErrTolForceAcc * P[target].OldAcc)
   GCHK(ghip_gather_f64(ctx, n, P<int>(ctx->gt.perm), P<double>(ctx->f[GHIP_F_OLDACC]),
                         P<double>(ctx->soldacc)));
-
-  int evi = (walk == GHIP_WALK_EWALD) ? 4 : 2;
-  HIPCHK(hipEventRecord(ctx->ev[evi], st));
-  launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, tgt, P<double>(ctx->sx),
-                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
-                  P<double>(ctx->soldacc), k, counter, plan);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[evi + 1], st));
-
-  k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(
-    nt, plan, tgt, P<int>(ctx->gt.perm), P<double>(ctx->tax), P<double>(ctx->tay),
-    P<double>(ctx->taz), P<int>(ctx->tcost), n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
-    P<int>(ctx->f[GHIP_F_GRAVCOST]), walk == GHIP_WALK_EWALD ? 1 : 0, k.debug_steps);
-  HIPCHK(hipGetLastError());
+  if(!pair)
+    {
+      GCHK(run_walk(ctx, A, nt, tgt, st));
+      return combine_walk(ctx, A, nt, tgt, st);
+    }
+  // Newtonian walk on the main stream, Ewald walk on the second one: the first is bound by fp64
+  // issue, the second by the table gathers, and a kernel's tail is filled by the other.  The
+  // Ewald sums are added after the Newtonian ones are in place (forcetree.c:3190-3193), and the
+  // main stream continues only when both are done.
+  hipStream_t s2 = ctx->stream2;
+  HIPCHK(hipEventRecord(ctx->evx[0], st));
+  HIPCHK(hipStreamWaitEvent(s2, ctx->evx[0], 0));
+  GCHK(run_walk(ctx, A, nt, tgt, st));
+  GCHK(run_walk(ctx, E, nt, tgt, s2));
+  GCHK(combine_walk(ctx, A, nt, tgt, st));
+  HIPCHK(hipEventRecord(ctx->evx[1], st));
+  HIPCHK(hipStreamWaitEvent(s2, ctx->evx[1], 0));
+  GCHK(combine_walk(ctx, E, nt, tgt, s2));
+  HIPCHK(hipEventRecord(ctx->evx[2], s2));
+  HIPCHK(hipStreamWaitEvent(st, ctx->evx[2], 0));
   return GHIP_OK;
 }
 
@@ -579,10 +643,11 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
   walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
   WalkPlan plan;
   GCHK(build_plan(ctx, 2, nbuckets, sg.ns, plan));
-  GCHK(ensure_partials(ctx, plan.nwaves));
+  PartialBufs pb;
+  GCHK(ensure_partials(ctx, plan.nwaves, 0, pb));
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 2;
   launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
-                  counter, plan);
+                  counter, plan, pb, st);
   k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, plan, nullptr, nullptr, P<double>(ctx->tax),
                                                P<double>(ctx->tay), P<double>(ctx->taz),
                                                P<int>(ctx->tcost), nt, dacc, dcost, 0, 0);

@@ -85,6 +85,11 @@ struct ghip_ctx
 
   // walk outputs in target order
   DevBuf tax, tay, taz, tcost;
+  // second set (slot 1) for the Ewald walk of an overlapped Newton+Ewald pair
+  DevBuf tax2, tay2, taz2, tcost2, plan_nsub2, plan_woff2, plan_wave2, cubtmp2;
+  hipStream_t stream2 = nullptr;   // the pair's Ewald walk runs here
+  hipEvent_t evx[3];               // pair ordering: inputs ready / Newton combined / Ewald combined
+  bool evx_ready = false;
   // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
   // visited per bucket in the previous call (double-buffered) and the scratch plan arrays
   DevBuf plan_steps[3][2], plan_nsub, plan_woff, plan_wave;

@@ -487,11 +487,10 @@ void gravity_tree(void)
   /* gravtree.c:96-100, 130-168: PMGRID -> short-range walk; PERIODIC && !PMGRID -> a second,
    * Ewald-correction walk */
   int walk = Cfg.pmgrid ? GHIP_WALK_SHORTRANGE : GHIP_WALK_NEWTON;
+  if(Cfg.periodic && !Cfg.pmgrid)
+    walk = GHIP_WALK_NEWTON_EWALD; /* both passes in one call: the two walks share the device */
   if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
     return;
-  if(Cfg.periodic && !Cfg.pmgrid)
-    if(chk(ghip_gravity(Ctx, &g, GHIP_WALK_EWALD), "ghip_gravity(ewald)"))
-      return;
   /* gravtree.c:381-403 */
   if(chk(ghip_gravity_finish(Ctx, All.G), "ghip_gravity_finish"))
     return;

@@ -80,8 +80,12 @@ class ShardedForceStep:
         collected at the end of the step and runs underneath the density kernels."""
         e = self.e
         e.tree_build(*tree_args)
-        for w in walks:
-            e.gravity(grav_params, w)
+        pair = getattr(e, "WALK_PAIR", None)
+        if pair is not None and list(walks) == [pair[0], pair[1]]:
+            e.gravity(grav_params, pair[2])     # both walks in one call: they share the device
+        else:
+            for w in walks:
+                e.gravity(grav_params, w)
         pending = self.exchange_begin(GROUP_GRAVITY)
         if has_gas:
             e.density(dens_params)

@@ -100,6 +100,10 @@ typedef struct
 #define GHIP_WALK_NEWTON 0      /* force_treeevaluate                   forcetree.c:1797 */
 #define GHIP_WALK_SHORTRANGE 1  /* force_treeevaluate_shortrange        forcetree.c:2330 */
 #define GHIP_WALK_EWALD 2       /* force_treeevaluate_ewald_correction  forcetree.c:2873 (adds) */
+#define GHIP_WALK_NEWTON_EWALD 3 /* both of gravity_tree's passes of a PERIODIC && !PMGRID build
+                                  * (gravtree.c:130-168) in one call: same results as 0 then 2, but
+                                  * the two walks share the device (one is bound by fp64 issue, the
+                                  * other by the table gathers) */
 
 typedef struct
 {

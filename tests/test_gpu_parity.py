@@ -179,6 +179,45 @@ def test_gravity_two_pass_parity(periodic):
         assert relerr(fp.get_field(B.F_GRAVACCEL), 3.0 * oacc) < TOL
 
 
+@pytest.mark.parametrize("subset", [False, True])
+def test_newton_ewald_pair_equals_the_two_calls(subset):
+    """GHIP_WALK_NEWTON_EWALD runs both passes of gravity_tree (gravtree.c:130-168) in one call with
+    the two walks sharing the device: counts identical, sums equal to rounding (the per-bucket
+    wavefront split, hence the grouping of partial sums, may differ between calls)."""
+    B = bindings()
+    pr = Problem(ng=14, gas=True, periodic=1)
+    fp = pr.device()
+    pr.device_tree(fp)
+    rng = np.random.default_rng(6)
+    old = 0.5 + rng.random(pr.n)
+    if subset:
+        fp.set_active(np.sort(rng.choice(pr.n, pr.n // 3, replace=False)).astype(np.int32))
+    res = []
+    for mode in ("two calls", "pair", "pair", "two calls"):
+        fp.set_field(B.F_OLDACC, old)
+        fp.set_field(B.F_GRAVACCEL, np.zeros((pr.n, 3)))
+        fp.set_field(B.F_GRAVCOST, np.zeros(pr.n, np.int32))
+        if mode == "pair":
+            fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+        else:
+            fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON)
+            fp.gravity(pr.g_grav(0.0), B.WALK_EWALD)
+        st = fp.stats()
+        res.append((fp.get_field(B.F_GRAVACCEL), fp.get_field(B.F_GRAVCOST),
+                    st["grav_interactions"], st["ewald_interactions"]))
+        assert st["ms_grav"] > 0 and st["ms_ewald"] > 0
+    for acc, cost, gi, ei in res[1:]:
+        assert np.array_equal(cost, res[0][1]) and gi == res[0][2] and ei == res[0][3]
+        assert np.abs(acc - res[0][0]).max() <= 1e-13 * np.abs(res[0][0]).max()
+    # and against the oracle
+    T = pr.oracle_tree()
+    tg = _all(pr.n) if not subset else np.where(np.any(res[1][0] != 0, axis=1))[0].astype(np.int32)
+    oacc, ocost = T.gravity(pr.o_grav(0.0), tg, old)
+    T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), tg, old, oacc, ocost)
+    assert np.array_equal(res[1][1][tg], ocost)
+    assert relerr(res[1][0][tg], oacc) < TOL
+
+
 def test_gravity_clustered_and_unequal_softenings():
     B = bindings()
     ic = ics.make_plummer(6000, gas_fraction=0.3)
