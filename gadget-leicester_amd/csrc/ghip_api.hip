@@ -41,6 +41,16 @@ int ghip_ensure(ghip_ctx *ctx, DevBuf &b, size_t bytes)
   return GHIP_OK;
 }
 
+int ghip_join(ghip_ctx *ctx)
+{
+  if(ctx && ctx->grav_pending)
+    {
+      ctx->grav_pending = false;
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evx[2], 0));
+    }
+  return GHIP_OK;
+}
+
 static void free_buf(DevBuf &b)
 {
   if(b.p)
@@ -81,7 +91,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         return GHIP_EHIP;
       }
   ctx->ev_ready = true;
-  if(hipStreamCreate(&ctx->stream2) != hipSuccess)
+  if(hipStreamCreate(&ctx->stream2) != hipSuccess || hipStreamCreate(&ctx->stream3) != hipSuccess)
     {
       delete ctx;
       return GHIP_EHIP;
@@ -125,6 +135,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     (void) hipStreamSynchronize(ctx->stream);
   if(ctx->stream2)
     (void) hipStreamSynchronize(ctx->stream2);
+  if(ctx->stream3)
+    (void) hipStreamSynchronize(ctx->stream3);
   for(int i = 0; i < GHIP_F_COUNT; i++)
     free_buf(ctx->f[i]);
   DevBuf *bs[] = {&ctx->stage,  &ctx->aosP,   &ctx->aosS,    &ctx->sx,      &ctx->sy,
@@ -156,6 +168,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
       (void) hipEventDestroy(ctx->evx[i]);
   if(ctx->stream2)
     (void) hipStreamDestroy(ctx->stream2);
+  if(ctx->stream3)
+    (void) hipStreamDestroy(ctx->stream3);
   if(ctx->stream)
     (void) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -168,11 +182,15 @@ extern "C" const char *ghip_last_error(const ghip_ctx *ctx)
 
 extern "C" void *ghip_stream(ghip_ctx *ctx)
 {
+  if(ctx)
+    (void) ghip_join(ctx);
   return ctx ? (void *) ctx->stream : nullptr;
 }
 
 extern "C" int ghip_sync(ghip_ctx *ctx)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx)
     return GHIP_EINVAL;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -211,6 +229,8 @@ static size_t field_bytes(const ghip_ctx *ctx, int f)
 
 extern "C" int ghip_set_counts(ghip_ctx *ctx, int numpart, int ngas)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || numpart < 0 || ngas < 0 || ngas > numpart)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_counts: need 0 <= ngas <= numpart");
   HIPCHK(hipSetDevice(ctx->device));
@@ -257,6 +277,8 @@ __global__ void k_soa_to_aos(size_t n, int ncomp, const T *__restrict__ src, T *
 
 extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || field < 0 || field >= GHIP_F_COUNT)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_field: bad field %d", field);
   size_t cnt = field_count(ctx, field), bytes = field_bytes(ctx, field);
@@ -286,6 +308,8 @@ extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
 
 extern "C" int ghip_get_field(ghip_ctx *ctx, int field, void *host)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || field < 0 || field >= GHIP_F_COUNT)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_get_field: bad field %d", field);
   size_t cnt = field_count(ctx, field), bytes = field_bytes(ctx, field);
@@ -378,6 +402,8 @@ __global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, in
 extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, const ghip_layout *lay,
                                int numpart, int ngas)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !lay || numpart < 0 || ngas < 0 || ngas > numpart || (numpart > 0 && !Pp) ||
      (ngas > 0 && !Sp))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad arguments");
@@ -443,6 +469,8 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
 extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
                                  int want_gravity, int want_density, int want_hydro)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !lay)
     return GHIP_EINVAL;
   size_t n = (size_t) ctx->n, ng = (size_t) ctx->ngas;
@@ -520,6 +548,8 @@ __global__ void k_pack_i32(size_t n, char *__restrict__ rec, int stride, int off
 // Ti_begstep; SphP[].VelPred, Entropy, e.DtEntropy)
 extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !lay)
     return GHIP_EINVAL;
   size_t n = (size_t) ctx->n, ng = (size_t) ctx->ngas;
@@ -560,6 +590,8 @@ extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const g
 // ---------------------------------------------------------------------------------------------
 extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || nactive < 0)
     return GHIP_EINVAL;
   if(!idx)
@@ -587,6 +619,8 @@ extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
 
 extern "C" int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || nranks < 1 || nranks > GHIP_MAXRANKS || rank < 0 || rank >= nranks)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_shard: need 0 <= rank < nranks <= %d",
                      GHIP_MAXRANKS);
@@ -600,6 +634,8 @@ extern "C" int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks)
 extern "C" int ghip_tree_build(ghip_ctx *ctx, const double corner[3], const double center[3],
                                double len, const double soft[6])
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !corner || !center || !soft || !(len > 0))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_build: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
@@ -619,6 +655,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   ghip_ctx *ctx = const_cast<ghip_ctx *>(cctx);
   if(!ctx || !out)
     return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ghip_stats &S = ctx->stats;
   if(ctx->counters.p)
@@ -653,6 +690,8 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
 extern "C" int ghip_tree_dump(ghip_ctx *ctx, int which, int *nelem, double *xm4, double *cl4,
                               int *lk4, double *aux, int *perm)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !nelem || which < 0 || which > 1)
     return GHIP_EINVAL;
   TreeDev &t = which ? ctx->st : ctx->gt;

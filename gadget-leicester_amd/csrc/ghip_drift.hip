@@ -80,6 +80,8 @@ __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
 
 extern "C" int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p)
     return GHIP_EINVAL;
   if(p->ComovingIntegrationOn && (!p->DriftTable || !p->GravKickTable || !p->HydroKickTable))

@@ -189,6 +189,8 @@ extern "C" int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int 
                                 void *Extnodes_base, int *Nextnode, int *Father, int max_nodes,
                                 int *numnodes)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !lay || !numnodes)
     return GHIP_EINVAL;
   TreeDev &t = ctx->gt;

@@ -162,6 +162,8 @@ __global__ void k_ewald_table(double inv_box2, double *__restrict__ tab)
 
 extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !(BoxSize > 0))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ewald_init: bad BoxSize");
   const int E1 = GHIP_EN + 1;
@@ -176,6 +178,8 @@ extern "C" int ghip_ewald_init(ghip_ctx *ctx, double BoxSize)
 
 extern "C" int ghip_ewald_get_table(ghip_ctx *ctx, double *host)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !host || ctx->ew_box == 0)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ewald_get_table: table not initialised");
   const int E1 = GHIP_EN + 1;
@@ -568,26 +572,30 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
       GCHK(run_walk(ctx, A, nt, tgt, st));
       return combine_walk(ctx, A, nt, tgt, st);
     }
-  // Newtonian walk on the main stream, Ewald walk on the second one: the first is bound by fp64
-  // issue, the second by the table gathers, and a kernel's tail is filled by the other.  The
-  // Ewald sums are added after the Newtonian ones are in place (forcetree.c:3190-3193), and the
-  // main stream continues only when both are done.
-  hipStream_t s2 = ctx->stream2;
+  // The two walks run on streams of their own: one is bound by fp64 issue, the other by the table
+  // gathers, and a kernel's tail is filled by the other.  The Ewald sums are added after the
+  // Newtonian ones are in place (forcetree.c:3190-3193).  The call returns with both in flight
+  // (ghip_join): what the host enqueues next on the main stream -- the SPH phases -- runs
+  // underneath them.
+  hipStream_t sN = ctx->stream3, sE = ctx->stream2;
   HIPCHK(hipEventRecord(ctx->evx[0], st));
-  HIPCHK(hipStreamWaitEvent(s2, ctx->evx[0], 0));
-  GCHK(run_walk(ctx, A, nt, tgt, st));
-  GCHK(run_walk(ctx, E, nt, tgt, s2));
-  GCHK(combine_walk(ctx, A, nt, tgt, st));
-  HIPCHK(hipEventRecord(ctx->evx[1], st));
-  HIPCHK(hipStreamWaitEvent(s2, ctx->evx[1], 0));
-  GCHK(combine_walk(ctx, E, nt, tgt, s2));
-  HIPCHK(hipEventRecord(ctx->evx[2], s2));
-  HIPCHK(hipStreamWaitEvent(st, ctx->evx[2], 0));
+  HIPCHK(hipStreamWaitEvent(sN, ctx->evx[0], 0));
+  HIPCHK(hipStreamWaitEvent(sE, ctx->evx[0], 0));
+  GCHK(run_walk(ctx, A, nt, tgt, sN));
+  GCHK(run_walk(ctx, E, nt, tgt, sE));
+  GCHK(combine_walk(ctx, A, nt, tgt, sN));
+  HIPCHK(hipEventRecord(ctx->evx[1], sN));
+  HIPCHK(hipStreamWaitEvent(sE, ctx->evx[1], 0));
+  GCHK(combine_walk(ctx, E, nt, tgt, sE));
+  HIPCHK(hipEventRecord(ctx->evx[2], sE));
+  ctx->grav_pending = true;
   return GHIP_OK;
 }
 
 extern "C" int ghip_gravity(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p)
     return GHIP_EINVAL;
   return ghip_gravity_impl(ctx, p, walk);
@@ -608,6 +616,8 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
                                 const double *pos, const int *type, const double *oldacc,
                                 double *acc, int *ninteractions)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p || nt < 0 || (nt > 0 && (!pos || !type || !oldacc || !acc || !ninteractions)))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_ext: bad arguments");
   if(!ctx->gt.built)
@@ -667,6 +677,8 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
 
 extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx)
     return GHIP_EINVAL;
   if(!ctx->gt.built)
@@ -687,6 +699,8 @@ extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
 // the sharded walks each rank holds all G-less accelerations)
 extern "C" int ghip_gravity_finish_all(ghip_ctx *ctx, double G)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx)
     return GHIP_EINVAL;
   if(!ctx->gt.built)
@@ -704,6 +718,8 @@ extern "C" int ghip_gravity_finish_all(ghip_ctx *ctx, double G)
 
 extern "C" int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p)
     return GHIP_EINVAL;
   if(!ctx->gt.built)

@@ -88,6 +88,8 @@ struct ghip_ctx
   // second set (slot 1) for the Ewald walk of an overlapped Newton+Ewald pair
   DevBuf tax2, tay2, taz2, tcost2, plan_nsub2, plan_woff2, plan_wave2, cubtmp2;
   hipStream_t stream2 = nullptr;   // the pair's Ewald walk runs here
+  hipStream_t stream3 = nullptr;   // ... and its Newtonian walk here, so the main stream stays free
+  bool grav_pending = false;       // a pair is in flight; evx[2] marks its end (see ghip_join)
   hipEvent_t evx[3];               // pair ordering: inputs ready / Newton combined / Ewald combined
   bool evx_ready = false;
   // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
@@ -116,6 +118,19 @@ struct ghip_ctx
 };
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
+// The overlapped Newton+Ewald pair returns with its walks still running on their own streams, so
+// that the SPH phases -- which read and write nothing the walks touch -- can be enqueued on the
+// main stream underneath them.  Every other entry point first makes the main stream wait for the
+// pair (GHIP_JOIN at its top).
+int ghip_join(ghip_ctx *ctx);
+#define GHIP_JOIN(ctx)                          \
+  do                                            \
+    {                                           \
+      int j_ = ghip_join(ctx);                  \
+      if(j_ != GHIP_OK)                         \
+        return j_;                              \
+    }                                           \
+  while(0)
 void ghip_pm_release(ghip_ctx *ctx);
 
 #define HIPCHK(call)                                                                         \

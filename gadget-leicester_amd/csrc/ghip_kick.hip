@@ -210,6 +210,8 @@ __global__ void k_timebin_histogram(int n, const int *__restrict__ type,
 extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
                                       long long *TimeBinCount, long long *TimeBinCountSph)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p)
     return GHIP_EINVAL;
   if(p->ComovingIntegrationOn && (!p->GravKickTable || !p->HydroKickTable))
@@ -385,6 +387,8 @@ __global__ void k_vel_moments_final(int nblocks, const double *__restrict__ pv2,
 extern "C" int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_mass[6],
                                      long long count[6])
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !v2sum || !min_mass || !count)
     return GHIP_EINVAL;
   int n = ctx->n;

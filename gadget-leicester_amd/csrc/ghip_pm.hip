@@ -172,6 +172,8 @@ __global__ void k_pm_interpolate(int n, int N, double to_slab_fac, const double 
 
 extern "C" int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p)
     return GHIP_EINVAL;
   const int N = p->pmgrid;

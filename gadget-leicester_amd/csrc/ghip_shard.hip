@@ -141,6 +141,8 @@ extern "C" int ghip_shard_pack(ghip_ctx *ctx, int group, void *dev_buf)
 {
   if(!ctx || group < 0 || group > 2 || !dev_buf)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_shard_pack: bad arguments");
+  if(group == 0)
+    GHIP_JOIN(ctx);   // the SPH groups may be exchanged underneath a gravity pair in flight
   if(!ctx->gt.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_shard_pack: no tree");
   GCHK(ghip_build_target_lists(ctx));
@@ -180,6 +182,8 @@ extern "C" int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_a
 {
   if(!ctx || group < 0 || group > 2 || !dev_buf_all || nranks != ctx->shard_n)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_shard_unpack: bad arguments");
+  if(group == 0)
+    GHIP_JOIN(ctx);
   if(!ctx->gt.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_shard_unpack: no tree");
   GCHK(ghip_build_target_lists(ctx));

@@ -656,6 +656,8 @@ extern "C" int ghip_update_hmax(ghip_ctx *ctx)
 extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, int target,
                                      double h, double out7[7])
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !p || !out7)
     return GHIP_EINVAL;
   if(!ctx->st.built)
@@ -756,6 +758,8 @@ __global__ void k_ngb_find(int nelem, const double4 *__restrict__ cl, const int4
 extern "C" int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double hsml, int pairs,
                                  int periodic, double boxsize, int *ngblist, int cap, int *nfound)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || !center || !nfound || cap < 0 || (cap > 0 && !ngblist))
     return GHIP_EINVAL;
   if(!ctx->st.built)

@@ -159,6 +159,8 @@ __global__ void k_peano_from_ints(int n, const int *__restrict__ x, const int *_
 extern "C" int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const int *y,
                                        const int *z, int bits, unsigned long long *keys)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || n < 0 || bits < 1 || bits > 21)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_peano_hilbert_keys: bad arguments");
   if(n == 0)
@@ -180,6 +182,8 @@ extern "C" int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const
 extern "C" int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y, const int *z,
                                 int bits, unsigned long long *keys)
 {
+  if(ctx)
+    GHIP_JOIN(ctx);
   if(!ctx || n < 0 || bits < 1 || bits > 21)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_morton_keys: bad arguments");
   if(n == 0)

@@ -76,24 +76,24 @@ class ShardedForceStep:
 
     def step(self, tree_args, grav_params, dens_params, hydro_params, G, walks, has_gas=True):
         """tree build -> gravity walks -> density -> hmax -> hydro, with the three exchanges.
-        Nothing in the SPH phases reads the gravity results, so their all-gather is only
-        collected at the end of the step and runs underneath the density kernels."""
+        Nothing in the SPH phases reads the gravity results: with the paired walk
+        (GHIP_WALK_NEWTON_EWALD) the gravity kernels are still running on their own streams when
+        the SPH phases are enqueued, and the gravity exchange comes last."""
         e = self.e
         e.tree_build(*tree_args)
         pair = getattr(e, "WALK_PAIR", None)
         if pair is not None and list(walks) == [pair[0], pair[1]]:
-            e.gravity(grav_params, pair[2])     # both walks in one call: they share the device
+            e.gravity(grav_params, pair[2])     # both walks in one call, returns with them in flight
         else:
             for w in walks:
                 e.gravity(grav_params, w)
-        pending = self.exchange_begin(GROUP_GRAVITY)
         if has_gas:
             e.density(dens_params)
             self.exchange(GROUP_DENSITY)
             e.update_hmax()
             e.hydro(hydro_params)
             self.exchange(GROUP_HYDRO)
-        self.exchange_end(pending)
+        self.exchange(GROUP_GRAVITY)
         if hasattr(e, "gravity_finish_all"):
             e.gravity_finish_all(G)    # OldAcc / G scaling for every particle, on every rank
         else:
