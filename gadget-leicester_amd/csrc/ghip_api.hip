@@ -41,7 +41,7 @@ int ghip_ensure(ghip_ctx *ctx, DevBuf &b, size_t bytes)
   return GHIP_OK;
 }
 
-int ghip_join(ghip_ctx *ctx)
+int ghip_join_pair(ghip_ctx *ctx)
 {
   if(ctx && ctx->grav_pending)
     {
@@ -49,6 +49,12 @@ int ghip_join(ghip_ctx *ctx)
       HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evx[2], 0));
     }
   return GHIP_OK;
+}
+
+int ghip_join(ghip_ctx *ctx)
+{
+  GCHK(ghip_join_pair(ctx));
+  return ctx ? ghip_finish_gas_tree(ctx) : GHIP_OK;
 }
 
 static void free_buf(DevBuf &b)

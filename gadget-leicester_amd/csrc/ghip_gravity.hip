@@ -595,7 +595,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 extern "C" int ghip_gravity(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 {
   if(ctx)
-    GHIP_JOIN(ctx);
+    GCHK(ghip_join_pair(ctx));   // (a deferred gas tree stays deferred: it is not needed here)
   if(!ctx || !p)
     return GHIP_EINVAL;
   return ghip_gravity_impl(ctx, p, walk);

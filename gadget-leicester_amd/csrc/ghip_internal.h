@@ -90,6 +90,10 @@ struct ghip_ctx
   hipStream_t stream2 = nullptr;   // the pair's Ewald walk runs here
   hipStream_t stream3 = nullptr;   // ... and its Newtonian walk here, so the main stream stays free
   bool grav_pending = false;       // a pair is in flight; evx[2] marks its end (see ghip_join)
+  // the second half of the gas tree build (elements, moments, SphNode records, gas records) is
+  // deferred to the first call that needs it, so that it runs underneath a gravity pair
+  bool gas_pending = false;
+  int gas_hinfo[3] = {0, 0, 0};
   hipEvent_t evx[3];               // pair ordering: inputs ready / Newton combined / Ewald combined
   bool evx_ready = false;
   // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
@@ -122,7 +126,9 @@ int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 // that the SPH phases -- which read and write nothing the walks touch -- can be enqueued on the
 // main stream underneath them.  Every other entry point first makes the main stream wait for the
 // pair (GHIP_JOIN at its top).
-int ghip_join(ghip_ctx *ctx);
+int ghip_join(ghip_ctx *ctx);        // wait for a pair in flight AND complete a deferred gas tree
+int ghip_join_pair(ghip_ctx *ctx);   // wait for a pair in flight only (entry of the gravity walks)
+int ghip_finish_gas_tree(ghip_ctx *ctx);   // complete a deferred gas tree (entry of the SPH phases)
 #define GHIP_JOIN(ctx)                          \
   do                                            \
     {                                           \

@@ -555,6 +555,7 @@ static int dens_alloc(ghip_ctx *ctx)
 
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 {
+  GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: call ghip_tree_build first");
   GCHK(ghip_build_target_lists(ctx));
@@ -648,6 +649,7 @@ extern "C" int ghip_update_hmax(ghip_ctx *ctx)
 {
   if(!ctx)
     return GHIP_EINVAL;
+  GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_update_hmax: no tree");
   return ghip_gastree_refresh_hmax(ctx);
@@ -660,6 +662,7 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
     GHIP_JOIN(ctx);
   if(!ctx || !p || !out7)
     return GHIP_EINVAL;
+  GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density_evaluate: no tree");
   if(target < 0 || target >= ctx->ngas)
@@ -762,6 +765,7 @@ extern "C" int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double h
     GHIP_JOIN(ctx);
   if(!ctx || !center || !nfound || cap < 0 || (cap > 0 && !ngblist))
     return GHIP_EINVAL;
+  GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_ngb_treefind: no tree");
   *nfound = 0;
@@ -1035,6 +1039,7 @@ __global__ void k_hydro_combine(int nt, int nsub, const int *__restrict__ tgt,
 
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
 {
+  GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_hydro: call ghip_tree_build first");
   GCHK(ghip_build_target_lists(ctx));

@@ -869,6 +869,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   tree_reset(ctx->gt, n);
   tree_reset(ctx->st, ng);
+  ctx->gas_pending = false;
   ctx->lists_dirty = true;
   ctx->stats.tree_nodes = ctx->stats.gastree_nodes = 0;
   if(n == 0)
@@ -921,29 +922,53 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   GCHK(ghip_build_segments(ctx, ctx->gt, true));
   GCHK(curve_order(ctx));
 
-  // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml
+  // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml.  Its order, node
+  // counts and curve order are known; the rest of its build is deferred to the first call that
+  // needs it (ghip_finish_gas_tree), which normally is ghip_density -- enqueued while a gravity
+  // pair is in flight, so that this work runs underneath the walks.
   if(ng > 0)
     {
-      GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
-      double *s = P<double>(ctx->stage);
-      GCHK(emit_tree(ctx, ctx->st, ng, hinfo + 4, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
-                     s + 3 * (size_t) ng, s + 4 * (size_t) ng, false));
-      ctx->st.built = true;
-      GCHK(ghip_sph_fill_nodes(ctx, false));
-      GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
-      GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
-      const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
-      k_gather_gas<<<cdiv(ng, 256), 256, 0, st>>>(
-        ng, P<int>(ctx->st.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
-        P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
-        P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
-        P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
-        P<double>(ctx->gq));
+      for(int q = 0; q < 3; q++)
+        ctx->gas_hinfo[q] = hinfo[4 + q];
+      ctx->st.nnodes = hinfo[5];
+      ctx->st.nelem = ng + hinfo[5];
+      ctx->gas_pending = true;
     }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   ctx->stats.tree_nodes = ctx->gt.nnodes;
   ctx->stats.gastree_nodes = ctx->st.nnodes;
+  return GHIP_OK;
+}
+
+int ghip_finish_gas_tree(ghip_ctx *ctx)
+{
+  if(!ctx->gas_pending)
+    return GHIP_OK;
+  ctx->gas_pending = false;
+  const int n = ctx->n, ng = ctx->ngas;
+  hipStream_t st = ctx->stream;
+  const double *x = P<double>(ctx->f[GHIP_F_POS]);
+  const double *y = x + n, *z = y + n;
+  const double *m = P<double>(ctx->f[GHIP_F_MASS]);
+  const double *h = P<double>(ctx->f[GHIP_F_HSML]);
+  GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) ng * 5 * sizeof(double)));
+  double *s = P<double>(ctx->stage);
+  GCHK(emit_tree(ctx, ctx->st, ng, ctx->gas_hinfo, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
+                 s + 3 * (size_t) ng, s + 4 * (size_t) ng, false));
+  ctx->st.built = true;
+  GCHK(ghip_sph_fill_nodes(ctx, false));
+  GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
+  GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
+  const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
+  k_gather_gas<<<cdiv(ng, 256), 256, 0, st>>>(
+    ng, P<int>(ctx->st.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
+    P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
+    P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
+    P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
+    P<double>(ctx->gq));
+  HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
 
@@ -1064,6 +1089,8 @@ int ghip_build_target_lists(ghip_ctx *ctx)
 {
   if(!ctx->lists_dirty)
     return GHIP_OK;
+  if(ctx->nactive >= 0)
+    GCHK(ghip_finish_gas_tree(ctx));   // an active subset is marked through st.iperm
   GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
   GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
   GCHK(permute_for_shards(ctx, ctx->tg_grav, ctx->nt_grav));
