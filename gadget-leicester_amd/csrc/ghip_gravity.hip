@@ -446,8 +446,16 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
     }
   int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
+  // In a pair the Newtonian walk must leave room for the Ewald walk: at its full 8 wavefronts per
+  // SIMD it owns the whole register file and the two kernels merely follow each other.  8 KB of
+  // (unused) dynamic LDS per one-wavefront workgroup caps it at 20 per CU = 5 per SIMD, which
+  // leaves registers for Ewald wavefronts next to them: 13.0 -> 11.4 ms per step at c2.
+  static int lds_n = -1;
+  if(lds_n < 0)
+    lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 8192;
+  const size_t dyn_lds = (MODE == GHIP_WALK_NEWTON && stream != ctx->stream) ? (size_t) lds_n : 0;
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
-  k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, 0, stream>>>(                                      \
+  k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
     P<float>(ctx->srtab), P<double>(ctx->ewtab), pb.ax, pb.ay, pb.az, pb.cost, counter, plan)
   // (the Ewald walk has no softening rule: one variant)
