@@ -433,7 +433,6 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
                         unsigned long long *counter, const WalkPlan &plan, const PartialBufs &pb,
                         hipStream_t stream)
 {
-  (void) nbuckets;
   long long nthreads = (long long) plan.nwaves * 64;
   // one wavefront per workgroup: wavefronts of a bucket finish at very different times, and a
   // 256-thread workgroup would hold its four slots until the slowest one is done
@@ -453,7 +452,10 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   static int lds_n = -1;
   if(lds_n < 0)
     lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 8192;
-  const size_t dyn_lds = (MODE == GHIP_WALK_NEWTON && stream != ctx->stream) ? (size_t) lds_n : 0;
+  // (only when the launch is large enough to fill the chip by itself: a small share of a
+  // multi-GPU run leaves room anyway -- measured break-even at about a quarter of c2's buckets)
+  const size_t dyn_lds =
+    (MODE == GHIP_WALK_NEWTON && stream != ctx->stream && nbuckets >= 3072) ? (size_t) lds_n : 0;
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \

@@ -30,3 +30,19 @@ for nr in (1, 2, 4, 8):
     print("1/%d of the buckets: tree %.3f grav %.3f ewald %.3f dens %.3f hmax %.3f hydro %.3f sum %.3f ms"
           % (nr, s["ms_tree"], s["ms_grav"], s["ms_ewald"], s["ms_dens"], s["ms_hmax"],
              s["ms_hydro"], tot), flush=True)
+
+# the same shares as ONE overlapped step (Newton+Ewald pair, SPH underneath): wall time per step
+import time
+for nr in (1, 2, 4, 8):
+    fp.set_shard(0, nr)
+    for rep in range(3):
+        if rep == 1:
+            fp.sync()
+            t0 = time.perf_counter()
+        pr.device_tree(fp)
+        fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+        fp.density(pr.g_dens())
+        fp.update_hmax()
+        fp.hydro(pr.g_hydro())
+    fp.sync()
+    print("1/%d overlapped step: %.3f ms wall" % (nr, (time.perf_counter() - t0) / 2 * 1e3), flush=True)
