@@ -127,6 +127,14 @@ def main():
     else:
         grav_int_all = float(grav_int)
 
+    # the dominant kernel alone (outside the timed region): in the timed steps it shares the chip
+    # with the Ewald walk and the SPH kernels, which stretches its own duration
+    iso = []
+    for _ in range(3):
+        fp.gravity(gp_rel, B.WALK_NEWTON)
+        iso.append(fp.stats()["ms_grav"])
+    iso_ms = float(np.median(iso))
+
     K = max(args.steps, 1)
     ms_per_step = 1e3 * elapsed / K
     value = pr.n * K / elapsed
@@ -180,6 +188,11 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": 1e3 * kern_s,
+                "note": "kernel_ms is the kernel's duration inside the timed steps, where it runs "
+                        "concurrently with the Ewald walk and the SPH kernels (DESIGN.md 4.3); "
+                        "kernel_ms_alone / frac_alone: the same launch with the chip to itself",
+                "kernel_ms_alone": iso_ms,
+                "frac_alone": (alg_bytes / (1e-3 * iso_ms) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else None,
                 "interactions_per_particle": grav_int_all / K / pr.n,
             },
             "phases_ms_rank0": {k: v / K for k, v in phase_ms.items()},
