@@ -85,7 +85,13 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
     return GHIP_ENOMEM;
   ctx->device = device;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
-  if(hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess)
+  // the main stream gets the highest priority, the two streams of a gravity pair the lowest: what
+  // is enqueued underneath the walks (SPH phases, the deferred gas-tree work) consists of short
+  // kernels that must not queue behind two chip-filling ones
+  int prio_least = 0, prio_greatest = 0;
+  if(hipSetDevice(device) != hipSuccess ||
+     hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+     hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, prio_greatest) != hipSuccess)
     {
       delete ctx;
       return GHIP_ENODEVICE;
@@ -97,7 +103,8 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         return GHIP_EHIP;
       }
   ctx->ev_ready = true;
-  if(hipStreamCreate(&ctx->stream2) != hipSuccess || hipStreamCreate(&ctx->stream3) != hipSuccess)
+  if(hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_least) != hipSuccess ||
+     hipStreamCreateWithPriority(&ctx->stream3, hipStreamDefault, prio_least) != hipSuccess)
     {
       delete ctx;
       return GHIP_EHIP;

@@ -127,6 +127,10 @@ int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 // main stream underneath them.  Every other entry point first makes the main stream wait for the
 // pair (GHIP_JOIN at its top).
 int ghip_join(ghip_ctx *ctx);        // wait for a pair in flight AND complete a deferred gas tree
+// Workgroup size of the short kernels that may run underneath a gravity pair: the walks use
+// one-wavefront workgroups, and a 256-thread workgroup -- which needs four free wavefront slots in
+// one CU at the same moment -- would starve behind them however high its stream's priority.
+static inline int ghip_wg(const ghip_ctx *ctx) { return ctx->grav_pending ? 64 : 256; }
 int ghip_join_pair(ghip_ctx *ctx);   // wait for a pair in flight only (entry of the gravity walks)
 int ghip_finish_gas_tree(ghip_ctx *ctx);   // complete a deferred gas tree (entry of the SPH phases)
 #define GHIP_JOIN(ctx)                          \

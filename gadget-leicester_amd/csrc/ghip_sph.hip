@@ -358,10 +358,10 @@ int ghip_sph_fill_nodes(ghip_ctx *ctx, bool hmax_only)
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(SphNode)));
   if(hmax_only)
-    k_sph_nodes_hmax<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double>(t.aux),
+    k_sph_nodes_hmax<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(t.nelem, P<double>(t.aux),
                                                                   P<SphNode>(t.mq));
   else
-    k_fill_sph_nodes<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(
+    k_fill_sph_nodes<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(
       t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<SphNode>(t.mq));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
@@ -580,7 +580,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   int *cur = P<int>(ctx->dtgt_a), *nxt = P<int>(ctx->dtgt_b);
   HIPCHK(hipMemcpyAsync(cur, P<int>(ctx->tg_gas) + lo, (size_t) nt * 4, hipMemcpyDeviceToDevice,
                         st));
-  k_dens_init<<<cdiv(nt, 256), 256, 0, st>>>(nt, cur, P<double>(ctx->gp), hcur,
+  k_dens_init<<<cdiv(nt, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(nt, cur, P<double>(ctx->gp), hcur,
                                              P<double>(ctx->dleft), P<double>(ctx->dright));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   DensFin F = {p->DesNumNgb, p->MaxNumNgbDeviation, p->MinGasHsml, p->Ti_Current,
@@ -602,7 +602,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
         t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur, nsub, cur, hcur, b, P<double>(ctx->drho),
         P<double>(ctx->dnumngb), P<double>(ctx->ddhsml), P<double>(ctx->ddivv),
         P<double>(ctx->drot), counter);
-      k_dens_finalize<<<cdiv(ncur, 256), 256, 0, st>>>(
+      k_dens_finalize<<<cdiv(ncur, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
         ncur, nsub, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
         P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
         P<double>(ctx->dleft), P<double>(ctx->dright), P<double>(ctx->f[GHIP_F_ENTROPY]),
@@ -1069,7 +1069,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
                                      P<double>(ctx->hpart), counter);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[11], st));
-  k_hydro_combine<<<cdiv(nt, 256), 256, 0, st>>>(
+  k_hydro_combine<<<cdiv(nt, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     nt, nsub, P<int>(ctx->tg_gas) + lo, P<int>(t.perm), P<double>(ctx->gq),
     P<double>(ctx->hpart), K, ng, P<double>(ctx->f[GHIP_F_HYDROACCEL]),
     P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]));

@@ -769,9 +769,9 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
   GCHK(ghip_ensure(ctx, t.cl, (size_t) t.nelem * sizeof(double4)));
   GCHK(ghip_ensure(ctx, t.lk, (size_t) t.nelem * sizeof(int4)));
   GCHK(ghip_ensure(ctx, t.aux, (size_t) t.nelem * sizeof(double)));
-  k_gather5<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
+  k_gather5<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
                                           P<int>(t.iperm));
-  k_emit_elements<<<cdiv(n, 256), 256, 0, st>>>(
+  k_emit_elements<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
     oz, om, oa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
     P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
@@ -779,10 +779,10 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
   for(int L = t.maxlevel; L >= 0; L--)
     {
       if(grav)
-        k_node_level<true, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+        k_node_level<true, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
           t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
       else
-        k_node_level<false, true><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+        k_node_level<false, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
           t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
     }
   HIPCHK(hipGetLastError());
@@ -962,7 +962,7 @@ int ghip_finish_gas_tree(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
   GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
   const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
-  k_gather_gas<<<cdiv(ng, 256), 256, 0, st>>>(
+  k_gather_gas<<<cdiv(ng, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     ng, P<int>(ctx->st.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
     P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
     P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
@@ -992,10 +992,10 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
     return GHIP_OK;
   hipStream_t st = ctx->stream;
   HIPCHK(hipEventRecord(ctx->ev[8], st));
-  k_aux_from_gp<<<cdiv(t.nelem, 256), 256, 0, st>>>(t.nelem, P<int4>(t.lk), P<double>(ctx->gp),
+  k_aux_from_gp<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(t.nelem, P<int4>(t.lk), P<double>(ctx->gp),
                                                    P<double>(t.aux));
   for(int L = t.maxlevel; L >= 0; L--)
-    k_node_level<false, false><<<cdiv(t.nelem, 256), 256, 0, st>>>(
+    k_node_level<false, false><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
       t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
   HIPCHK(hipGetLastError());
   GCHK(ghip_sph_fill_nodes(ctx, true));
