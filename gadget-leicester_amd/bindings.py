@@ -75,7 +75,8 @@ class KickParams(C.Structure):
                 ("dt_displacement", C.c_double), ("SofteningTable", C.c_double * 6),
                 ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint),
                 ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double),
-                ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p)]
+                ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p),
+                ("AdaptiveGravsoftForGasHsml", C.c_int)]
 
 
 class PmParams(C.Structure):
@@ -88,7 +89,7 @@ class NodeLayout(C.Structure):
     _fields_ = [(k, C.c_int) for k in
                 ("node_stride", "n_len", "n_center", "n_s", "n_mass", "n_bitflags", "n_sibling",
                  "n_nextnode", "n_father", "n_ti_current", "ext_stride", "e_dp", "e_vs", "e_vmax",
-                 "e_divvmax", "e_hmax", "e_ti_lastkicked", "e_flag")]
+                 "e_divvmax", "e_hmax", "e_ti_lastkicked", "e_flag", "n_maxsoft")]
 
 
 # struct NODE / struct extNODE of the minimal periodic flag set (88 / 80 bytes)
@@ -96,6 +97,12 @@ NODE_DTYPE = np.dtype({"names": ["len", "center", "s", "mass", "bitflags", "sibl
                                  "father", "Ti_current"],
                        "formats": ["f8", ("f8", 3), ("f8", 3), "f8", "u4", "i4", "i4", "i4", "i4"],
                        "offsets": [0, 8, 32, 56, 64, 68, 72, 76, 80], "itemsize": 88})
+# struct NODE with ADAPTIVE_GRAVSOFT_FORGAS: maxsoft sits before the union (allvars.h:1857-1860), 96 bytes
+NODE_ADAPTIVE_DTYPE = np.dtype({"names": ["len", "center", "maxsoft", "s", "mass", "bitflags",
+                                          "sibling", "nextnode", "father", "Ti_current"],
+                                "formats": ["f8", ("f8", 3), "f8", ("f8", 3), "f8", "u4", "i4", "i4",
+                                            "i4", "i4"],
+                                "offsets": [0, 8, 32, 40, 64, 72, 76, 80, 84, 88], "itemsize": 96})
 EXTNODE_DTYPE = np.dtype({"names": ["dp", "vs", "vmax", "divVmax", "hmax", "Ti_lastkicked", "Flag"],
                           "formats": [("f8", 3), ("f8", 3), "f8", "f8", "f8", "i4", "i4"],
                           "offsets": [0, 24, 48, 56, 64, 72, 76], "itemsize": 80})
@@ -134,7 +141,7 @@ EXPORTS = [
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
-    "ghip_tree_export", "ghip_pm_periodic"]
+    "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft"]
 
 
 def lib():
@@ -161,6 +168,9 @@ def lib():
         L.ghip_gravity.argtypes = [vp, C.POINTER(GravParams), C.c_int]
         L.ghip_gravity_ext.argtypes = [vp, C.POINTER(GravParams), C.c_int, C.c_int, vp, vp, vp,
                                        vp, vp]
+        L.ghip_gravity_ext_soft.argtypes = [vp, C.POINTER(GravParams), C.c_int, C.c_int, vp, vp, vp,
+                                            vp, vp, vp]
+        L.ghip_set_adaptive_gravsoft.argtypes = [vp, C.c_int]
         L.ghip_gravity_finish.argtypes = [vp, C.c_double]
         L.ghip_gravity_finish_all.argtypes = [vp, C.c_double]
         L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
@@ -291,16 +301,23 @@ class ForcePath:
     def gravity(self, params, walk=WALK_NEWTON):
         self._chk(self.L.ghip_gravity(self.h, C.byref(params), int(walk)))
 
-    def gravity_ext(self, params, pos, ptype, oldacc, walk=WALK_NEWTON):
+    def gravity_ext(self, params, pos, ptype, oldacc, walk=WALK_NEWTON, soft=None):
+        """soft: gravdata_in.Soft (Hsml of gas targets), used under set_adaptive_gravsoft."""
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         ptype = np.ascontiguousarray(ptype, dtype=np.int32)
         oldacc = np.ascontiguousarray(oldacc, dtype=np.float64)
+        soft = None if soft is None else np.ascontiguousarray(soft, dtype=np.float64)
         nt = len(pos)
         acc = np.zeros((nt, 3))
         nint = np.zeros(nt, np.int32)
-        self._chk(self.L.ghip_gravity_ext(self.h, C.byref(params), int(walk), nt, _ptr(pos),
-                                          _ptr(ptype), _ptr(oldacc), _ptr(acc), _ptr(nint)))
+        self._chk(self.L.ghip_gravity_ext_soft(self.h, C.byref(params), int(walk), nt, _ptr(pos),
+                                               _ptr(ptype), None if soft is None else _ptr(soft),
+                                               _ptr(oldacc), _ptr(acc), _ptr(nint)))
         return acc, nint
+
+    def set_adaptive_gravsoft(self, on=True):
+        """ADAPTIVE_GRAVSOFT_FORGAS: gas softening = Hsml; call before tree_build."""
+        self._chk(self.L.ghip_set_adaptive_gravsoft(self.h, int(bool(on))))
 
     def gravity_finish(self, G):
         self._chk(self.L.ghip_gravity_finish(self.h, float(G)))
@@ -340,24 +357,27 @@ class ForcePath:
                 raise
         return np.array(cnt[:], dtype=np.int64), np.array(sph[:], dtype=np.int64)
 
-    def tree_export(self, maxpart=None, ti_current=0, unequal=0, max_nodes=None):
-        """ghip_tree_export into numpy records of the minimal-flag-set NODE / extNODE layout;
+    def tree_export(self, maxpart=None, ti_current=0, unequal=0, max_nodes=None, adaptive=False):
+        """ghip_tree_export into numpy records of the minimal-flag-set NODE / extNODE layout
+        (adaptive: the 96-byte NODE of an ADAPTIVE_GRAVSOFT_FORGAS build, with maxsoft);
         returns (Nodes, Extnodes, Nextnode, Father) with Nodes[k] = node maxpart + k."""
         maxpart = self.n if maxpart is None else int(maxpart)
         max_nodes = int(2.0 * maxpart + 16) if max_nodes is None else int(max_nodes)
         lay = NodeLayout()
-        lay.node_stride = NODE_DTYPE.itemsize
+        ndt = NODE_ADAPTIVE_DTYPE if adaptive else NODE_DTYPE
+        lay.node_stride = ndt.itemsize
+        lay.n_maxsoft = ndt.fields["maxsoft"][1] if adaptive else -1
         for name, key in (("len", "n_len"), ("center", "n_center"), ("s", "n_s"), ("mass", "n_mass"),
                           ("bitflags", "n_bitflags"), ("sibling", "n_sibling"),
                           ("nextnode", "n_nextnode"), ("father", "n_father"),
                           ("Ti_current", "n_ti_current")):
-            setattr(lay, key, NODE_DTYPE.fields[name][1])
+            setattr(lay, key, ndt.fields[name][1])
         lay.ext_stride = EXTNODE_DTYPE.itemsize
         for name, key in (("dp", "e_dp"), ("vs", "e_vs"), ("vmax", "e_vmax"),
                           ("divVmax", "e_divvmax"), ("hmax", "e_hmax"),
                           ("Ti_lastkicked", "e_ti_lastkicked"), ("Flag", "e_flag")):
             setattr(lay, key, EXTNODE_DTYPE.fields[name][1])
-        nodes = np.zeros(max_nodes, NODE_DTYPE)
+        nodes = np.zeros(max_nodes, ndt)
         ext = np.zeros(max_nodes, EXTNODE_DTYPE)
         nxt = np.full(maxpart, -1, np.int32)
         fat = np.full(maxpart, -1, np.int32)

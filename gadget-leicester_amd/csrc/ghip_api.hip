@@ -663,6 +663,17 @@ extern "C" int ghip_tree_build(ghip_ctx *ctx, const double corner[3], const doub
   return ghip_tree_build_impl(ctx);
 }
 
+extern "C" int ghip_set_adaptive_gravsoft(ghip_ctx *ctx, int on)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  if(ctx->adaptive_gravsoft != (on != 0))
+    ctx->gt.built = false;   // particle and node softenings are baked into the element records
+  ctx->adaptive_gravsoft = (on != 0);
+  return GHIP_OK;
+}
+
 extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
 {
   ghip_ctx *ctx = const_cast<ghip_ctx *>(cctx);

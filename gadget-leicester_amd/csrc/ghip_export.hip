@@ -100,7 +100,7 @@ __global__ void k_ext_level(int nelem, int level, const int4 *__restrict__ lk,
 struct ExportK
 {
   ghip_node_layout lay;
-  int maxpart, ti_current, unequal;
+  int maxpart, ti_current, unequal, adaptive;
   double soft[6];
 };
 
@@ -156,7 +156,9 @@ __global__ void k_export(int nelem, ExportK K, const int4 *__restrict__ lk,
     }
   d_put<double>(nd, K.lay.n_mass, m.w);
   unsigned int flags = ecnt[e] > 1 ? (1u << BITFLAG_MULTIPLEPARTICLES) : 0u;
-  if(K.unequal)
+  if(K.adaptive)
+    d_put<double>(nd, K.lay.n_maxsoft, fabs(aux[e]));   // forcetree.c:845-846
+  else if(K.unequal)
     {
       // forcetree.c:612-700 (UNEQUALSOFTENINGS): type of the largest softening below, mixed flag
       double a = aux[e];
@@ -237,6 +239,7 @@ extern "C" int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int 
   K.maxpart = MaxPart;
   K.ti_current = Ti_Current;
   K.unequal = unequal_softenings;
+  K.adaptive = ctx->adaptive_gravsoft;
   for(int q = 0; q < 6; q++)
     K.soft[q] = ctx->soft[q];
   k_export<<<cdiv(nelem, 256), 256, 0, st>>>(nelem, K, P<int4>(t.lk), P<double4>(t.cl),

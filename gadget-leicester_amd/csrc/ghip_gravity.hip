@@ -207,7 +207,7 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.boxsize = p->BoxSize;
   k.boxhalf = 0.5 * p->BoxSize;
   k.periodic = p->periodic;
-  k.unequal = p->unequal_softenings;
+  k.unequal = p->unequal_softenings || ctx->adaptive_gravsoft;   // the latter implies the former
   k.rcut = p->Rcut;
   k.rcut2 = p->Rcut * p->Rcut;
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
@@ -611,20 +611,9 @@ extern "C" int ghip_gravity(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   return ghip_gravity_impl(ctx, p, walk);
 }
 
-__global__ void k_soft_of_type_g(int n, const int *__restrict__ type, double s0, double s1,
-                                 double s2, double s3, double s4, double s5,
-                                 double *__restrict__ out)
-{
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  int t = type[i];
-  out[i] = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
-}
-
-extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
-                                const double *pos, const int *type, const double *oldacc,
-                                double *acc, int *ninteractions)
+extern "C" int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
+                                     const double *pos, const int *type, const double *soft,
+                                     const double *oldacc, double *acc, int *ninteractions)
 {
   if(ctx)
     GHIP_JOIN(ctx);
@@ -641,23 +630,26 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
   hipStream_t st = ctx->stream;
   // staging: x,y,z,oldacc,soft (f64[nt]) + combined acc (3 f64[nt]) + type, cost (i32[nt])
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nt * (8 * 8 + 2 * 4) + 64));
-  std::vector<double> h((size_t) nt * 4);
+  std::vector<double> h((size_t) nt * 5);
   for(int a = 0; a < nt; a++)
     {
+      if(type[a] < 0 || type[a] > 5)
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_ext: target %d has type %d", a, type[a]);
       h[a] = pos[3 * (size_t) a];
       h[(size_t) nt + a] = pos[3 * (size_t) a + 1];
       h[2 * (size_t) nt + a] = pos[3 * (size_t) a + 2];
       h[3 * (size_t) nt + a] = oldacc[a];
+      // the target's own softening: gravdata_in.Soft for gas under ADAPTIVE_GRAVSOFT_FORGAS
+      // (forcetree.c:1875-1878), All.ForceSoftening[Type] otherwise
+      h[4 * (size_t) nt + a] = (ctx->adaptive_gravsoft && type[a] == 0 && soft)
+                                 ? soft[a]
+                                 : p->ForceSoftening[type[a]];
     }
   double *dx = P<double>(ctx->stage), *dy = dx + nt, *dz = dy + nt, *dold = dz + nt,
          *dsoft = dold + nt, *dacc = dsoft + nt;
   int *dtype = reinterpret_cast<int *>(dacc + 3 * (size_t) nt), *dcost = dtype + nt;
-  HIPCHK(hipMemcpyAsync(dx, h.data(), (size_t) nt * 32, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dx, h.data(), (size_t) nt * 40, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(dtype, type, (size_t) nt * 4, hipMemcpyHostToDevice, st));
-  k_soft_of_type_g<<<cdiv(nt, 256), 256, 0, st>>>(nt, dtype, p->ForceSoftening[0],
-                                                  p->ForceSoftening[1], p->ForceSoftening[2],
-                                                  p->ForceSoftening[3], p->ForceSoftening[4],
-                                                  p->ForceSoftening[5], dsoft);
   WalkSeg sg;
   int nbuckets;
   walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
@@ -683,6 +675,13 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
       acc[3 * (size_t) a + 2] = r[2 * (size_t) nt + a];
     }
   return GHIP_OK;
+}
+
+extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
+                                const double *pos, const int *type, const double *oldacc,
+                                double *acc, int *ninteractions)
+{
+  return ghip_gravity_ext_soft(ctx, p, walk, nt, pos, type, nullptr, oldacc, acc, ninteractions);
 }
 
 extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)

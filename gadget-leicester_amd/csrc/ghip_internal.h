@@ -89,6 +89,7 @@ struct ghip_ctx
   DevBuf tax2, tay2, taz2, tcost2, plan_nsub2, plan_woff2, plan_wave2, cubtmp2;
   hipStream_t stream2 = nullptr;   // the pair's Ewald walk runs here
   hipStream_t stream3 = nullptr;   // ... and its Newtonian walk here, so the main stream stays free
+  bool adaptive_gravsoft = false;   // ADAPTIVE_GRAVSOFT_FORGAS: gas softening = Hsml (ghip_set_adaptive_gravsoft)
   bool grav_pending = false;       // a pair is in flight; evx[2] marks its end (see ghip_join)
   // the second half of the gas tree build (elements, moments, SphNode records, gas records) is
   // deferred to the first call that needs it, so that it runs underneath a gravity pair

@@ -33,6 +33,7 @@ struct KickK
   double time, hubble_a, fac1, fac2, fac3, a3inv, atime;   // timestep.c:52-63
   double errtol, courant, maxdt, mindt, dtdisp;
   double soft[6];
+  int adaptive_hsml;
   double minegy;
   unsigned int active;
   DriftK tab;   // gravkick / hydrokick tables (comoving)
@@ -75,6 +76,8 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
   if(ac == 0)
     ac = 1.0e-30;
   double dt = sqrt(2 * k.errtol * k.atime * k.soft[ty] / ac);
+  if(k.adaptive_hsml && ty == 0)   // timestep.c:740-743
+    dt = sqrt(2 * k.errtol * k.atime * hsml[i] / 2.8 / ac);
   if(gas)
     {
       double dt_courant;
@@ -252,6 +255,7 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   k.dtdisp = p->dt_displacement;
   for(int t = 0; t < 6; t++)
     k.soft[t] = p->SofteningTable[t];
+  k.adaptive_hsml = p->AdaptiveGravsoftForGasHsml;
   k.minegy = p->MinEgySpec;
   k.active = p->TimeBinActive;
   k.tab.timebase = p->Timebase_interval;

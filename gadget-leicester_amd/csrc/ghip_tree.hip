@@ -347,7 +347,7 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
 template <bool GRAV, bool MOMENTS>
 __global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
                              const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-                             double *__restrict__ aux)
+                             double *__restrict__ aux, bool adaptive)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if(e >= nelem)
@@ -412,7 +412,9 @@ __global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
         }
       xm[e] = make_double4(sx, sy, sz, mass);
     }
-  aux[e] = (GRAV && mixed) ? -amax : amax;
+  // ADAPTIVE_GRAVSOFT_FORGAS: NODE.maxsoft opens the node for every target inside it, mixed or not
+  // (forcetree.c:2125-2139)
+  aux[e] = (GRAV && (mixed || adaptive)) ? -amax : amax;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -780,10 +782,11 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
     {
       if(grav)
         k_node_level<true, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux),
+          ctx->adaptive_gravsoft);
       else
         k_node_level<false, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), false);
     }
   HIPCHK(hipGetLastError());
   return GHIP_OK;
@@ -840,14 +843,18 @@ static int curve_order(ghip_ctx *ctx)
   return GHIP_OK;
 }
 
+// hsml != nullptr: ADAPTIVE_GRAVSOFT_FORGAS, a gas particle is softened with its Hsml
+// (forcetree.c:705-716, 1851-1856, 2038-2058)
 __global__ void k_soft_of_type(int n, const int *__restrict__ type, double s0, double s1, double s2,
-                               double s3, double s4, double s5, double *__restrict__ out)
+                               double s3, double s4, double s5, const double *__restrict__ hsml,
+                               double *__restrict__ out)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
   int t = type[i];
-  out[i] = (t == 0) ? s0 : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+  out[i] = (t == 0) ? (hsml ? hsml[i] : s0)
+                    : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
 }
 
 static void tree_reset(TreeDev &t, int n)
@@ -891,7 +898,10 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   double *tmp_soft = P<double>(ctx->soldacc);  // scratch until the first gravity call
   k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
                                                ctx->soft[1], ctx->soft[2], ctx->soft[3],
-                                               ctx->soft[4], ctx->soft[5], tmp_soft);
+                                               ctx->soft[4], ctx->soft[5],
+                                               ctx->adaptive_gravsoft ? P<double>(ctx->f[GHIP_F_HSML])
+                                                                      : nullptr,
+                                               tmp_soft);
 
   bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
   for(;;)
@@ -996,7 +1006,7 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
                                                    P<double>(t.aux));
   for(int L = t.maxlevel; L >= 0; L--)
     k_node_level<false, false><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-      t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+      t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), false);
   HIPCHK(hipGetLastError());
   GCHK(ghip_sph_fill_nodes(ctx, true));
   HIPCHK(hipEventRecord(ctx->ev[9], st));

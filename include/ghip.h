@@ -157,6 +157,8 @@ typedef struct
   unsigned int TimeBinActive; /* bit b set <=> TimeBinActive[b] (timestep.c:163) */
   double logTimeBegin, logTimeMax;                /* driftfac.c:20 */
   const double *GravKickTable, *HydroKickTable;   /* host, 1000 entries each; comoving only */
+  int AdaptiveGravsoftForGasHsml; /* ADAPTIVE_GRAVSOFT_FORGAS + _HSML: the gravity criterion of a
+                                     gas particle uses Hsml/2.8 as its softening (timestep.c:740-743) */
 } ghip_kick_params;
 
 /* "next" row N2: byte offsets of struct NODE / struct extNODE (allvars.h:1847-1916) as the host
@@ -166,6 +168,7 @@ typedef struct
   int node_stride, n_len, n_center, n_s, n_mass, n_bitflags, n_sibling, n_nextnode, n_father,
     n_ti_current;
   int ext_stride, e_dp, e_vs, e_vmax, e_divvmax, e_hmax, e_ti_lastkicked, e_flag;
+  int n_maxsoft;   /* NODE.maxsoft (allvars.h:1857-1860, ADAPTIVE_GRAVSOFT_FORGAS builds only) */
 } ghip_node_layout;
 
 /* "next" row N3: periodic particle-mesh long-range force (pmforce_periodic, pm_periodic.c:199) */
@@ -272,6 +275,12 @@ int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p);
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
                     double DomainLen, const double ForceSoftening[6]);
+/* ADAPTIVE_GRAVSOFT_FORGAS (the shipped Makefile bundle): on != 0 makes the gravitational softening
+ * of a gas particle its Hsml instead of ForceSoftening[0], as a target (forcetree.c:1851-1856), as
+ * a source (:2038-2058) and in the nodes' maxsoft (:705-726, 845-846), which then opens a node
+ * whenever the target lies inside it (:2125-2139).  Implies UNEQUALSOFTENINGS.  The softenings are
+ * captured by ghip_tree_build: call this before it (it invalidates a built tree). */
+int ghip_set_adaptive_gravsoft(ghip_ctx *ctx, int on);
 int ghip_ewald_init(ghip_ctx *ctx, double BoxSize);
 /* host copy of the ewald table [3][65][65][65] already scaled by 1/BoxSize^2 */
 int ghip_ewald_get_table(ghip_ctx *ctx, double *host);
@@ -287,6 +296,11 @@ int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
 int ghip_gravity_finish(ghip_ctx *ctx, double G);
 /* the same for ALL active particles regardless of the shard (multi-GPU: after the all-gather) */
 int ghip_gravity_finish_all(ghip_ctx *ctx, double G);
+/* the same with gravdata_in.Soft (allvars.h:1695, gravtree.c:214-220): soft[a] = Hsml of a gas
+ * target, used when ghip_set_adaptive_gravsoft is on; NULL = ghip_gravity_ext */
+int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
+                          const double *pos, const int *type, const double *soft,
+                          const double *oldacc, double *acc, int *ninteractions);
 /* softened direct summation over all particles for the active targets (accuracy oracle on
  * device, formula of forcetree.c:4273-4336); writes GRAVACCEL */
 int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p);

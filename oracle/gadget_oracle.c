@@ -132,6 +132,7 @@ struct orc_tree
   const int *type;
   double soft[6];
   int last;
+  int adaptive;         /* ADAPTIVE_GRAVSOFT_FORGAS: a gas particle's softening is its Hsml */
 };
 
 #define NODE(t, no) ((t)->nodes[(no) - (t)->n])
@@ -598,6 +599,40 @@ static inline double grav_fac(double mass, double r2, double r, double h)
                           0.066666666667 / (u * u * u));
 }
 
+/* softening of particle i: All.ForceSoftening[type], or its Hsml for gas under
+ * ADAPTIVE_GRAVSOFT_FORGAS (forcetree.c:1851-1856, 2038-2058) */
+static inline double particle_soft(const orc_tree *t, int i)
+{
+  if(t->adaptive && t->type[i] == 0)
+    return t->hsml ? t->hsml[i] : 0;
+  return t->soft[t->type[i]];
+}
+
+/* ADAPTIVE_GRAVSOFT_FORGAS (forcetree.c:535-541, 634-635, 705-726, 845-846): NODE.maxsoft = the
+ * largest softening below, gas particles counting with Hsml; the walk then opens a node whenever
+ * the target lies inside that softening (forcetree.c:2125-2139), so mixedsoft is set throughout.
+ * Children are created after their parents, so one reverse sweep sees every child first. */
+void orc_tree_adaptive_gravsoft(orc_tree *t)
+{
+  t->adaptive = 1;
+  for(int k = t->numnodes - 1; k >= 0; k--)
+    {
+      onode *nd = &t->nodes[k];
+      double maxsoft = 0;
+      for(int j = 0; j < 8; j++)
+        {
+          int p = nd->suns[j];
+          if(p < 0)
+            continue;
+          double sp = (p >= t->n) ? NODE(t, p).maxsoft : particle_soft(t, p);
+          if(sp > maxsoft)
+            maxsoft = sp;
+        }
+      nd->maxsoft = maxsoft;
+      nd->mixedsoft = 1;
+    }
+}
+
 static float shortrange_table[ORC_NTAB];
 static int shortrange_ready = 0;
 
@@ -616,14 +651,17 @@ static void shortrange_init(void)
 
 /* forcetree.c:1797-2317 (shortrange == 0) and forcetree.c:2330-2845 (shortrange == 1) */
 static int treeevaluate(const orc_tree *t, const orc_grav_params *p, int shortrange,
-                        const double tpos[3], int ptype, double oldacc, double acc[3])
+                        const double tpos[3], int ptype, double tsoft, double oldacc, double acc[3])
 {
+  /* tsoft: the target's own softening (All.ForceSoftening[ptype]; Hsml of a gas target under
+   * ADAPTIVE_GRAVSOFT_FORGAS, forcetree.c:1851-1856 / gravdata_in.Soft :1875-1878) */
+  const int unequal = p->unequal_softenings || t->adaptive;
   double pos_x = tpos[0], pos_y = tpos[1], pos_z = tpos[2];
   double aold = p->ErrTolForceAcc * oldacc;
   double boxsize = p->BoxSize, boxhalf = 0.5 * p->BoxSize;
   double acc_x = 0, acc_y = 0, acc_z = 0;
   int ninteractions = 0;
-  double h = t->soft[ptype];
+  double h = tsoft;
   double rcut = p->rcut, rcut2 = rcut * rcut;
   double asmthfac = shortrange ? 0.5 / p->asmth * (ORC_NTAB / 3.0) : 0;
 
@@ -644,11 +682,11 @@ static int treeevaluate(const orc_tree *t, const orc_grav_params *p, int shortra
               dz = nearest(dz, boxsize, boxhalf);
             }
           r2 = dx * dx + dy * dy + dz * dz;
-          if(p->unequal_softenings)
+          if(unequal)
             {
-              h = t->soft[ptype];
-              if(h < t->soft[t->type[no]])
-                h = t->soft[t->type[no]];
+              h = tsoft;
+              if(h < particle_soft(t, no))
+                h = particle_soft(t, no);
             }
           no = t->nextnode[no];
         }
@@ -730,10 +768,10 @@ static int treeevaluate(const orc_tree *t, const orc_grav_params *p, int shortra
                     }
             }
 
-          if(p->unequal_softenings)
+          if(unequal)
             {
-              /* forcetree.c:2108-2124 */
-              h = t->soft[ptype];
+              /* forcetree.c:2108-2139 */
+              h = tsoft;
               if(h < nop->maxsoft)
                 {
                   h = nop->maxsoft;
@@ -785,16 +823,27 @@ void orc_gravity(const orc_tree *t, const orc_grav_params *p, int nt, const int 
   for(int a = 0; a < nt; a++)
     {
       int i = targets[a];
-      cost[a] = treeevaluate(t, p, 0, &t->pos[3 * i], t->type[i], oldacc[i], &acc[3 * a]);
+      cost[a] = treeevaluate(t, p, 0, &t->pos[3 * i], t->type[i], particle_soft(t, i), oldacc[i],
+                             &acc[3 * a]);
+    }
+}
+
+void orc_gravity_ext_soft(const orc_tree *t, const orc_grav_params *p, int nt, const double *tpos,
+                          const int *ttype, const double *tsoft, const double *toldacc, double *acc,
+                          int *cost)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+  for(int a = 0; a < nt; a++)
+    {
+      double h = (t->adaptive && ttype[a] == 0 && tsoft) ? tsoft[a] : t->soft[ttype[a]];
+      cost[a] = treeevaluate(t, p, 0, &tpos[3 * a], ttype[a], h, toldacc[a], &acc[3 * a]);
     }
 }
 
 void orc_gravity_ext(const orc_tree *t, const orc_grav_params *p, int nt, const double *tpos,
                      const int *ttype, const double *toldacc, double *acc, int *cost)
 {
-#pragma omp parallel for schedule(dynamic, 64)
-  for(int a = 0; a < nt; a++)
-    cost[a] = treeevaluate(t, p, 0, &tpos[3 * a], ttype[a], toldacc[a], &acc[3 * a]);
+  orc_gravity_ext_soft(t, p, nt, tpos, ttype, NULL, toldacc, acc, cost);
 }
 
 void orc_gravity_shortrange(const orc_tree *t, const orc_grav_params *p, int nt,
@@ -805,7 +854,8 @@ void orc_gravity_shortrange(const orc_tree *t, const orc_grav_params *p, int nt,
   for(int a = 0; a < nt; a++)
     {
       int i = targets[a];
-      cost[a] = treeevaluate(t, p, 1, &t->pos[3 * i], t->type[i], oldacc[i], &acc[3 * a]);
+      cost[a] = treeevaluate(t, p, 1, &t->pos[3 * i], t->type[i], particle_soft(t, i), oldacc[i],
+                             &acc[3 * a]);
     }
 }
 
@@ -1035,9 +1085,10 @@ void orc_gravity_ewald(const orc_tree *t, const orc_grav_params *p, const double
 }
 
 /* independent check: softened direct summation (formula of forcetree.c:4273-4336) */
-void orc_gravity_direct(int n, const double *pos, const double *mass, const int *type,
-                        const double soft[6], int unequal, int periodic, double boxsize,
-                        const double *ewald_tab, int nt, const int *targets, double *acc)
+static void gravity_direct_impl(int n, const double *pos, const double *mass, const int *type,
+                                const double soft[6], const double *psoft, int unequal, int periodic,
+                                double boxsize, const double *ewald_tab, int nt, const int *targets,
+                                double *acc)
 {
   double boxhalf = 0.5 * boxsize;
   double fac_intp = periodic ? 2 * ORC_EN / boxsize : 0;
@@ -1058,9 +1109,10 @@ void orc_gravity_direct(int n, const double *pos, const double *mass, const int 
               dz = nearest(dz, boxsize, boxhalf);
             }
           double r2 = dx * dx + dy * dy + dz * dz;
-          double h = soft[type[i]];
-          if(unequal && h < soft[type[j]])
-            h = soft[type[j]];
+          double h = psoft ? psoft[i] : soft[type[i]];
+          double hj = psoft ? psoft[j] : soft[type[j]];
+          if(unequal && h < hj)
+            h = hj;
           double r = sqrt(r2);
           double fac = grav_fac(mass[j], r2, r, h);
           ax += dx * fac;
@@ -1079,6 +1131,24 @@ void orc_gravity_direct(int n, const double *pos, const double *mass, const int 
       acc[3 * a + 1] = ay;
       acc[3 * a + 2] = az;
     }
+}
+
+void orc_gravity_direct(int n, const double *pos, const double *mass, const int *type,
+                        const double soft[6], int unequal, int periodic, double boxsize,
+                        const double *ewald_tab, int nt, const int *targets, double *acc)
+{
+  gravity_direct_impl(n, pos, mass, type, soft, NULL, unequal, periodic, boxsize, ewald_tab, nt,
+                      targets, acc);
+}
+
+/* the same with one softening per particle (ADAPTIVE_GRAVSOFT_FORGAS: Hsml for gas,
+ * ForceSoftening[type] otherwise), pairs softened with the larger of the two */
+void orc_gravity_direct_psoft(int n, const double *pos, const double *mass, const double *psoft,
+                              int periodic, double boxsize, const double *ewald_tab, int nt,
+                              const int *targets, double *acc)
+{
+  gravity_direct_impl(n, pos, mass, NULL, NULL, psoft, 1, periodic, boxsize, ewald_tab, nt, targets,
+                      acc);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1795,6 +1865,8 @@ int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive
       if(ac == 0)
         ac = 1.0e-30;
       double dt = sqrt(2 * p->ErrTolIntAccuracy * atime * p->SofteningTable[type[i]] / ac);
+      if(p->AdaptiveGravsoftForGasHsml && type[i] == 0) /* timestep.c:740-743 */
+        dt = sqrt(2 * p->ErrTolIntAccuracy * atime * hsml[i] / 2.8 / ac);
       if(type[i] == 0)
         {
           double dt_courant;

@@ -46,6 +46,10 @@ orc_tree *orc_tree_build(int n, const double *pos, const double *vel, const doub
                          const int *type, const double *hsml, const double *divvel,
                          const double soft[6], const double corner[3], const double center[3],
                          double len, int toplevels);
+/* switch the built tree to ADAPTIVE_GRAVSOFT_FORGAS (gas softening = Hsml; NODE.maxsoft,
+ * forcetree.c:535-541, 705-726, 845-846): every later gravity walk over it uses those rules
+ * (forcetree.c:1851-1856, 2038-2058, 2125-2139) */
+void orc_tree_adaptive_gravsoft(orc_tree *t);
 void orc_tree_free(orc_tree *t);
 int orc_tree_numnodes(const orc_tree *t);
 /* node dump for tests: arrays sized numnodes; index k is node (n + k) */
@@ -78,6 +82,11 @@ void orc_gravity(const orc_tree *t, const orc_grav_params *p, int nt, const int 
  * allvars.h:1690-1703, walking the whole local tree) */
 void orc_gravity_ext(const orc_tree *t, const orc_grav_params *p, int nt, const double *tpos,
                      const int *ttype, const double *toldacc, double *acc, int *cost);
+/* the same with gravdata_in.Soft (allvars.h:1695): tsoft[a] = Hsml of a gas target, used under
+ * ADAPTIVE_GRAVSOFT_FORGAS; may be NULL */
+void orc_gravity_ext_soft(const orc_tree *t, const orc_grav_params *p, int nt, const double *tpos,
+                          const int *ttype, const double *tsoft, const double *toldacc, double *acc,
+                          int *cost);
 /* force_treeevaluate_shortrange (forcetree.c:2330-2845) */
 void orc_gravity_shortrange(const orc_tree *t, const orc_grav_params *p, int nt,
                             const int *targets, const double *oldacc, double *acc, int *cost);
@@ -93,6 +102,9 @@ void orc_gravity_ewald(const orc_tree *t, const orc_grav_params *p, const double
 void orc_gravity_direct(int n, const double *pos, const double *mass, const int *type,
                         const double soft[6], int unequal, int periodic, double boxsize,
                         const double *ewald_tab, int nt, const int *targets, double *acc);
+void orc_gravity_direct_psoft(int n, const double *pos, const double *mass, const double *psoft,
+                              int periodic, double boxsize, const double *ewald_tab, int nt,
+                              const int *targets, double *acc);
 
 /* ---- neighbour search (ngb.c:169-297, 32-160): returns count, writes indices ---- */
 int orc_ngb_treefind_variable(const orc_tree *t, const double c[3], double h, int periodic,
@@ -163,6 +175,7 @@ typedef struct
   unsigned int TimeBinActive; /* bit b: TimeBinActive[b] */
   const double *tables;       /* [3][1000] drift, gravkick, hydrokick */
   double logTimeBegin, logTimeMax;
+  int AdaptiveGravsoftForGasHsml; /* ADAPTIVE_GRAVSOFT_FORGAS(_HSML): timestep.c:740-743 */
 } orc_kick_params;
 
 void orc_velocity_moments(int n, const double *vel, const double *mass, const int *type,

@@ -65,6 +65,11 @@ def lib():
         L.orc_gravity.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.orc_gravity_shortrange.argtypes = L.orc_gravity.argtypes
         L.orc_gravity_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_gravity_ext_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.orc_tree_adaptive_gravsoft.argtypes = [C.c_void_p]
+        L.orc_gravity_direct_psoft.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p]
         L.orc_gravity_ewald.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.orc_ewald_init.argtypes = [C.c_void_p, C.c_double]
         L.orc_ewald_force.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -219,15 +224,21 @@ class Tree:
         lib().orc_gravity_ewald(self.h, C.byref(params), _p(tab), len(targets), _p(targets),
                                 _p(oldacc), _p(acc), _p(cost))
 
-    def gravity_ext(self, params, tpos, ttype, toldacc):
+    def gravity_ext(self, params, tpos, ttype, toldacc, tsoft=None):
         tpos = _f64(tpos)
         ttype = _i32(ttype)
         toldacc = _f64(toldacc)
+        tsoft = None if tsoft is None else _f64(tsoft)
         acc = np.zeros((len(tpos), 3))
         cost = np.zeros(len(tpos), np.int32)
-        lib().orc_gravity_ext(self.h, C.byref(params), len(tpos), _p(tpos), _p(ttype),
-                              _p(toldacc), _p(acc), _p(cost))
+        lib().orc_gravity_ext_soft(self.h, C.byref(params), len(tpos), _p(tpos), _p(ttype),
+                                   _p(tsoft), _p(toldacc), _p(acc), _p(cost))
         return acc, cost
+
+    def adaptive_gravsoft(self):
+        """ADAPTIVE_GRAVSOFT_FORGAS: gas softening = Hsml, NODE.maxsoft (forcetree.c:705-726)."""
+        lib().orc_tree_adaptive_gravsoft(self.h)
+        return self
 
     # ---- neighbours ----
     def ngb_variable(self, c, h, periodic, boxsize):
@@ -304,6 +315,18 @@ def gravity_direct(pos, mass, ptype, soft, targets, unequal=False, periodic=Fals
     return acc
 
 
+def gravity_direct_psoft(pos, mass, psoft, targets, periodic=False, boxsize=1.0, ewald_tab=None):
+    """Direct sum with one softening per particle, pairs softened with the larger one."""
+    pos = _f64(pos)
+    mass = _f64(mass)
+    psoft = _f64(psoft)
+    targets = _i32(targets)
+    acc = np.zeros((len(targets), 3))
+    lib().orc_gravity_direct_psoft(len(pos), _p(pos), _p(mass), _p(psoft), int(periodic),
+                                   float(boxsize), _p(ewald_tab), len(targets), _p(targets), _p(acc))
+    return acc
+
+
 def drift(time1, timebase, pos, vel, ptype, ti_current, timebin, ti_begstep, gravaccel, velpred,
           hydroaccel, density, hsml, divvel, entropy, dtentropy, pressure, minhsml=0.0, wrap=False,
           boxsize=1.0, tables=None, log_time_begin=0.0, log_time_max=0.0):
@@ -334,7 +357,8 @@ class KickParams(C.Structure):
                 ("MaxSizeTimestep", C.c_double), ("MinSizeTimestep", C.c_double),
                 ("dt_displacement", C.c_double), ("SofteningTable", C.c_double * 6),
                 ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint), ("tables", C.c_void_p),
-                ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double)]
+                ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double),
+                ("AdaptiveGravsoftForGasHsml", C.c_int)]
 
 
 def velocity_moments(vel, mass, ptype):

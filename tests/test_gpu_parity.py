@@ -242,6 +242,72 @@ def test_gravity_clustered_and_unequal_softenings():
     assert relerr(fp.get_field(B.F_GRAVACCEL), d) < 1e-10
 
 
+@pytest.mark.parametrize("periodic", [0, 1])
+def test_adaptive_gravsoft_forgas_parity(periodic):
+    """ADAPTIVE_GRAVSOFT_FORGAS (the shipped Makefile bundle, config c5): a gas particle is softened
+    with its Hsml -- as target, as source, and through NODE.maxsoft, which opens every node the
+    target lies inside of.  Smoothing lengths are spread over a decade so that the rule decides
+    many node openings; interaction counts must still be the insertion tree walk's, bit for bit.
+    Pinned independently by a direct sum with one softening per particle."""
+    B = bindings()
+    ic = ics.make_plummer(6000, gas_fraction=0.4) if not periodic else ics.make_ics(14, gas=True)
+    pr = Problem(ic=ic, periodic=periodic, unequal=True)
+    n, ng = pr.n, pr.ngas
+    rng = np.random.default_rng(8)
+    hs = pr.hsml0.copy()
+    hs[:ng] *= 0.1 + 1.2 * rng.random(ng)
+    fp = pr.device()
+    fp.set_field(B.F_HSML, hs)
+    fp.set_adaptive_gravsoft(True)
+    pr.device_tree(fp)
+    T = pr.oracle_tree(hsml=hs).adaptive_gravsoft()
+    tg = _all(n)
+    # the exported tree carries maxsoft in the 96-byte NODE of such a build
+    nodes, ext, nxt, fat = fp.tree_export(adaptive=True)
+    od = T.dump()
+    key_g = np.column_stack([nodes["len"], nodes["center"]])
+    key_o = np.column_stack([od["len"], od["center"]])
+    og, oo = np.lexsort(key_g.T[::-1]), np.lexsort(key_o.T[::-1])
+    assert np.array_equal(key_g[og], key_o[oo])
+    assert np.array_equal(nodes["maxsoft"][og], od["maxsoft"][oo])
+    assert nodes["maxsoft"][0] == max(hs[:ng].max(), pr.force_soft[ic["type"]].max())
+    assert np.all(nodes["bitflags"] & ~np.uint32(1 << 7) == 0)      # no softening-type bits then
+    old = np.zeros(n)
+    for theta in (0.6, 0.0):
+        fp.set_field(B.F_OLDACC, old)
+        fp.gravity(pr.g_grav(theta), B.WALK_NEWTON)
+        oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+        assert np.array_equal(fp.get_field(B.F_GRAVCOST), ocost)
+        assert relerr(fp.get_field(B.F_GRAVACCEL), oacc) < TOL
+        old = np.linalg.norm(oacc, axis=1)
+    # the rule matters on this input: the fixed-softening walk visits different interaction lists
+    fp2 = pr.device()
+    fp2.set_field(B.F_HSML, hs)
+    fp2.set_field(B.F_OLDACC, np.zeros(n))
+    pr.device_tree(fp2)
+    fp2.gravity(pr.g_grav(0.6), B.WALK_NEWTON)
+    _, c06 = T.gravity(pr.o_grav(0.6), tg, np.zeros(n))
+    assert not np.array_equal(fp2.get_field(B.F_GRAVCOST), c06)
+    # imported targets bring their own softening (gravdata_in.Soft)
+    ne = 300
+    epos = ic["pos"][rng.integers(0, n, ne)] + 1e-3 * rng.standard_normal((ne, 3))
+    if periodic:
+        epos %= pr.box
+    etype = (rng.random(ne) < 0.5).astype(np.int32)
+    esoft = np.where(etype == 0, np.median(hs[:ng]) * (0.2 + 3 * rng.random(ne)), 0.0)
+    eold = np.full(ne, np.median(old))
+    eacc, enint = fp.gravity_ext(pr.g_grav(0.0), epos, etype, eold, soft=esoft)
+    xacc, xcost = T.gravity_ext(pr.o_grav(0.0), epos, etype, eold, tsoft=esoft)
+    assert np.array_equal(enint, xcost)
+    assert relerr(eacc, xacc) < TOL
+    # independent pin: direct summation with per-particle softening
+    psoft = np.where(ic["type"] == 0, hs, pr.force_soft[ic["type"]])
+    fp.gravity_direct(pr.g_grav(0.0))
+    d = O.gravity_direct_psoft(ic["pos"], ic["mass"], psoft, tg, periodic=bool(periodic),
+                               boxsize=pr.box)
+    assert relerr(fp.get_field(B.F_GRAVACCEL), d) < 1e-10
+
+
 @pytest.mark.parametrize("clump", [20, 90])
 def test_tight_clumps_sort_paths(clump):
     """Particles closer than 2^-11 of the domain share the top 32 key bits: short runs are ordered
@@ -884,14 +950,17 @@ def _fill(P, par, soft):
 
 @pytest.mark.parametrize("comoving", [False, True])
 @pytest.mark.parametrize("subset", [False, True])
-def test_timestep_and_kick_parity(comoving, subset):
+@pytest.mark.parametrize("adaptive", [0, 1])
+def test_timestep_and_kick_parity(comoving, subset, adaptive):
     """advance_and_find_timesteps / get_timestep / do_the_kick on the resident fields against the
     CPU restatement: TimeBin, Ti_begstep and the bin counts exactly, the kicked quantities to
-    bit (no fma contraction in that file)."""
+    bit (no fma contraction in that file).  adaptive: the gravity criterion of gas uses Hsml/2.8
+    (ADAPTIVE_GRAVSOFT_FORGAS_HSML, timestep.c:740-743)."""
     B = bindings()
     pr = Problem(ng=10, gas=True, periodic=1)
     n, ng = pr.n, pr.ngas
     st, par, tabs = _kick_case(pr, comoving)
+    par["AdaptiveGravsoftForGasHsml"] = adaptive
     soft = pr.force_soft / 2.8
     fp = pr.device()
     hfull = pr.hsml0.copy()

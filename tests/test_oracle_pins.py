@@ -92,6 +92,37 @@ def test_tree_walk_converges_to_direct_summation(periodic):
         assert np.median(err) < 2e-2 and err.max() < 0.3
 
 
+def test_adaptive_gravsoft_walk_converges_to_a_direct_sum_with_per_particle_softening():
+    """ADAPTIVE_GRAVSOFT_FORGAS (forcetree.c:705-726, 1851-1856, 2038-2058, 2125-2139): gas is
+    softened with Hsml.  Pins: (i) with a tiny opening angle the walk equals the direct sum whose
+    pairs take the larger of the two particles' softenings; (ii) maxsoft of the root is the largest
+    softening present; (iii) no target ever uses a node it lies inside the softening of -- so even
+    at theta = 0.6 the error stays at the usual monopole level."""
+    rng = np.random.default_rng(1)
+    n = 2000
+    pos = rng.random((n, 3))
+    mass = np.full(n, 1.0 / n)
+    typ = (np.arange(n) % 2).astype(np.int32)
+    soft = np.array([0.01, 0.02, 0, 0, 0, 0])
+    hs = np.where(typ == 0, 0.03 + 0.05 * rng.random(n), 0.0)
+    t = O.Tree(pos, None, mass, typ, soft, hsml=hs).adaptive_gravsoft()
+    gp = O.GravParams(1e-3, 0.0, 1.0, 0, 1, 0.0, 0.0)
+    tg = np.arange(0, n, 7, dtype=np.int32)
+    psoft = np.where(typ == 0, hs, soft[typ])
+    d = O.gravity_direct_psoft(pos, mass, psoft, tg)
+    acc, cost = t.gravity(gp, tg, np.zeros(n))
+    assert relerr(acc, d) < 1e-13 and np.all(cost == n)
+    dump = t.dump()
+    assert dump["maxsoft"][0] == psoft.max() and np.all(dump["mixedsoft"] == 1)
+    gp.ErrTolTheta = 0.6
+    acc, cost = t.gravity(gp, tg, np.zeros(n))
+    assert np.abs(acc - d).max() < 0.05 * np.abs(d).max() and cost.mean() < 0.2 * n
+    # the fixed-softening walk over the same particles gives different forces: the flag matters
+    t0 = O.Tree(pos, None, mass, typ, soft, hsml=hs)
+    acc0, _ = t0.gravity(gp, tg, np.zeros(n))
+    assert np.abs(acc0 - acc).max() > 0.05 * np.abs(d).max()
+
+
 def test_relative_criterion_is_more_accurate_than_bh():
     pr = Problem(ic=ics.make_plummer(3000), periodic=0)
     T = pr.oracle_tree()
@@ -329,6 +360,20 @@ def test_timestep_and_kick_restatement_against_hand_evaluation():
     half = (1 << int(out["timebin"][1])) // 2 * tb
     assert out["entropy"][1] + out["dtentropy"][1] * half >= 0.5 * out["entropy"][1] * (1 - 1e-15)
     assert out["bincount"].sum() == 4 and out["bincount_sph"].sum() == 2
+    # ADAPTIVE_GRAVSOFT_FORGAS_HSML (timestep.c:740-743): gas takes Hsml/2.8 as its softening in the
+    # gravity criterion.  A tiny Hsml makes that criterion the binding one for gas particle 0.
+    P.AdaptiveGravsoftForGasHsml = 1
+    hs2 = np.array([2.8e-4, 0.1])
+    out2 = O.advance_timesteps(P, ptype, vel, grav, hyd, vel[:ng].copy(), entropy, dtentropy,
+                               np.ones(ng), np.ones(ng), hs2, vsig, timebin, tbeg)
+    a0 = grav[0] + hyd[0]
+    dt0 = min(np.sqrt(2 * 0.025 * 1e-4 / np.sqrt((a0 * a0).sum())), 2 * 0.15 * hs2[0] / vsig[0])
+    step = TIMEBASE
+    while step > int(dt0 / tb):
+        step >>= 1
+    assert out2["rc"] == 0 and out2["timebin"][0] == step.bit_length() - 1 < out["timebin"][0]
+    assert np.array_equal(out2["timebin"][2:], out["timebin"][2:])     # other types unaffected
+    P.AdaptiveGravsoftForGasHsml = 0
     # failure paths carry the reference's endrun codes
     P.MinSizeTimestep = 1.0
     assert O.advance_timesteps(P, ptype, vel, grav, hyd, vel[:ng].copy(), entropy, dtentropy,
