@@ -208,6 +208,57 @@ void set_softenings(void)
   All.MinGasHsml = All.MinGasHsmlFractional * All.ForceSoftening[0];
 }
 
+/* gravtree.c:892-907 */
+int data_index_compare(const void *a, const void *b)
+{
+  const struct data_index *x = (const struct data_index *) a, *y = (const struct data_index *) b;
+  if(x->Task != y->Task)
+    return x->Task < y->Task ? -1 : +1;
+  if(x->Index != y->Index)
+    return x->Index < y->Index ? -1 : +1;
+  return 0;
+}
+
+/* gravtree.c:909-963: stable sort of data_index records.  Bottom-up merge between the array and
+ * one scratch copy (the reference recurses top-down; the result of a stable sort is unique). */
+void mysort_dataindex(void *b, size_t n, size_t s, int (*cmp)(const void *, const void *))
+{
+  if(n < 2 || s != sizeof(struct data_index))
+    {
+      if(n >= 2)
+        qsort(b, n, s, cmp);
+      return;
+    }
+  struct data_index *src = (struct data_index *) b;
+  struct data_index *tmp = (struct data_index *) malloc(n * sizeof(struct data_index));
+  if(!tmp)
+    {
+      endrun(90004);
+      return;
+    }
+  struct data_index *dst = tmp;
+  for(size_t w = 1; w < n; w *= 2)
+    {
+      for(size_t lo = 0; lo < n; lo += 2 * w)
+        {
+          size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+          size_t i = lo, j = mid, k = lo;
+          while(i < mid && j < hi)
+            dst[k++] = (cmp(&src[j], &src[i]) < 0) ? src[j++] : src[i++];
+          while(i < mid)
+            dst[k++] = src[i++];
+          while(j < hi)
+            dst[k++] = src[j++];
+        }
+      struct data_index *t = src;
+      src = dst;
+      dst = t;
+    }
+  if(src != (struct data_index *) b)
+    memcpy(b, src, n * sizeof(struct data_index));
+  free(tmp);
+}
+
 /* darkenergy.c:389-409 without DARKENERGY */
 double hubble_function(double a)
 {

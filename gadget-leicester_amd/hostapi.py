@@ -71,7 +71,8 @@ ENDRUN_CB = C.CFUNCTYPE(None, C.c_int)
 
 EXPORTS = ["gadget_force_init", "gadget_force_finalize", "gadget_force_last_error",
            "gadget_force_ctx", "gadget_force_layout", "gadget_force_set_endrun",
-           "gadget_force_mark_dirty", "endrun", "set_softenings", "domain_findExtent",
+           "gadget_force_mark_dirty", "endrun", "set_softenings", "data_index_compare",
+           "mysort_dataindex", "domain_findExtent",
            "force_treebuild", "ewald_init", "gravity_tree", "density", "density_isactive",
            "force_update_hmax", "hydro_force", "force_treeevaluate",
            "force_treeevaluate_shortrange", "force_treeevaluate_ewald_correction",

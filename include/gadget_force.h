@@ -150,6 +150,15 @@ struct global_data_all_processes
   int TypeOfTimestepCriterion, StarformationOn;
 };
 
+/* allvars.h:1673-1684: export bookkeeping record other translation units sort with the two
+ * functions below (blackhole.c:366, dust.c:114, density.c:186 ...) */
+struct data_index
+{
+  int Task;
+  int Index;
+  int IndexGet;
+};
+
 /* gravdata_in / gravdata_out, allvars.h:1690-1716 (mode == 1 records) */
 struct gravdata_in
 {
@@ -255,6 +264,10 @@ void gadget_force_mark_dirty(void);
 /* ---- the reference's call surface ---- */
 void endrun(int ierr);
 void set_softenings(void);
+/* gravtree.c:892-907 (order by Task, then Index) and :909-963 (a stable sort of data_index records
+ * with that interface; they live in gravtree.c, which this library replaces) */
+int data_index_compare(const void *a, const void *b);
+void mysort_dataindex(void *b, size_t n, size_t s, int (*cmp)(const void *, const void *));
 void domain_findExtent(void);
 int force_treebuild(int npart, void *mp);
 void ewald_init(void);
