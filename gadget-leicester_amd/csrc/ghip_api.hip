@@ -109,7 +109,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       delete ctx;
       return GHIP_EHIP;
     }
-  for(int i = 0; i < 3; i++)
+  for(int i = 0; i < 4; i++)
     if(hipEventCreateWithFlags(&ctx->evx[i], hipEventDisableTiming) != hipSuccess)
       {
         delete ctx;
@@ -177,7 +177,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
   if(ctx->evx_ready)
-    for(int i = 0; i < 3; i++)
+    for(int i = 0; i < 4; i++)
       (void) hipEventDestroy(ctx->evx[i]);
   if(ctx->stream2)
     (void) hipStreamDestroy(ctx->stream2);

@@ -593,6 +593,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   HIPCHK(hipStreamWaitEvent(sE, ctx->evx[0], 0));
   GCHK(run_walk(ctx, A, nt, tgt, sN));
   GCHK(run_walk(ctx, E, nt, tgt, sE));
+  HIPCHK(hipEventRecord(ctx->evx[3], sE));   // the Ewald walk's wavefront slots are free from here on
   GCHK(combine_walk(ctx, A, nt, tgt, sN));
   HIPCHK(hipEventRecord(ctx->evx[1], sN));
   HIPCHK(hipStreamWaitEvent(sE, ctx->evx[1], 0));

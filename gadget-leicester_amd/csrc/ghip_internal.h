@@ -95,7 +95,8 @@ struct ghip_ctx
   // deferred to the first call that needs it, so that it runs underneath a gravity pair
   bool gas_pending = false;
   int gas_hinfo[3] = {0, 0, 0};
-  hipEvent_t evx[3];               // pair ordering: inputs ready / Newton combined / Ewald combined
+  hipEvent_t evx[4];               // pair ordering: inputs ready / Newton combined / Ewald combined /
+                                   // Ewald walk kernel done (ghip_hydro waits for it)
   bool evx_ready = false;
   // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
   // visited per bucket in the previous call (double-buffered) and the scratch plan arrays

@@ -16,7 +16,6 @@
 // share a bucket, each taking every n-th candidate batch; their partial sums are added in fixed
 // order.  Neighbour SETS are geometric, so they are identical to the reference's; only the
 // summation order differs.
-#include <hipcub/hipcub.hpp>
 
 #include "ghip_internal.h"
 
@@ -553,6 +552,73 @@ static int dens_alloc(ghip_ctx *ctx)
   return GHIP_OK;
 }
 
+// Order-preserving selection of the flagged entries of the target list (the not yet converged
+// particles of an h-iteration, density.c:566-660).  Three small launches of one-wavefront
+// workgroups instead of a library select: its single-pass look-back kernel needs 256-thread
+// workgroups to make progress in order, and underneath a gravity pair -- where the density
+// iterations normally run -- they wait milliseconds for four free wave slots on one CU.
+#define SEL_ITEMS 16
+#define SEL_BLOCK (64 * SEL_ITEMS)
+
+__global__ void __launch_bounds__(64) k_sel_count(int n, const int *__restrict__ flags,
+                                                  int *__restrict__ blockcnt)
+{
+  const int base = blockIdx.x * SEL_BLOCK;
+  int c = 0;
+  for(int j = 0; j < SEL_ITEMS; j++)
+    {
+      const int a = base + j * 64 + threadIdx.x;
+      c += (a < n && flags[a] != 0) ? 1 : 0;
+    }
+  for(int o = 32; o > 0; o >>= 1)
+    c += __shfl_down(c, o, 64);
+  if(threadIdx.x == 0)
+    blockcnt[blockIdx.x] = c;
+}
+
+// counts -> exclusive offsets (in place), total to *total; one wavefront
+__global__ void __launch_bounds__(64) k_sel_scan(int nblk, int *__restrict__ blockcnt,
+                                                 int *__restrict__ total)
+{
+  int run = 0;
+  for(int b0 = 0; b0 < nblk; b0 += 64)
+    {
+      const int b = b0 + threadIdx.x;
+      const int c = b < nblk ? blockcnt[b] : 0;
+      int incl = c;
+      for(int o = 1; o < 64; o <<= 1)
+        {
+          const int v = __shfl_up(incl, o, 64);
+          if((int) threadIdx.x >= o)
+            incl += v;
+        }
+      if(b < nblk)
+        blockcnt[b] = run + incl - c;
+      run += __shfl(incl, 63, 64);
+    }
+  if(threadIdx.x == 0)
+    *total = run;
+}
+
+__global__ void __launch_bounds__(64) k_sel_scatter(int n, const int *__restrict__ in,
+                                                    const int *__restrict__ flags,
+                                                    const int *__restrict__ blockoff,
+                                                    int *__restrict__ out)
+{
+  const int base = blockIdx.x * SEL_BLOCK;
+  int off = blockoff[blockIdx.x];
+  const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+  for(int j = 0; j < SEL_ITEMS; j++)
+    {
+      const int a = base + j * 64 + threadIdx.x;
+      const bool keep = a < n && flags[a] != 0;
+      const unsigned long long m = __ballot(keep);
+      if(keep)
+        out[off + __popcll(m & below)] = in[a];
+      off += __popcll(m);
+    }
+}
+
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 {
   GCHK(ghip_finish_gas_tree(ctx));
@@ -587,9 +653,8 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
                p->Timebase_interval};
   int maxiter = p->MaxIter > 0 ? p->MaxIter : 150;
   int ncur = nt, iter = 0;
-  size_t tb = 0;
-  HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, cur, P<int>(ctx->dflags), nxt, dnum, nt, st));
-  GCHK(ghip_ensure(ctx, ctx->cubtmp, tb + 256));
+  GCHK(ghip_ensure(ctx, ctx->cubtmp, ((size_t) cdiv(nt, SEL_BLOCK) + 2) * 4));
+  int *seloff = P<int>(ctx->cubtmp);
 
   while(ncur > 0)
     {
@@ -614,12 +679,18 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
         P<double>(ctx->f[GHIP_F_PRESSURE]), P<int>(ctx->dflags));
       HIPCHK(hipGetLastError());
       S.dens_target_evals += ncur;
-      size_t tb2 = ctx->cubtmp.cap;
-      HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb2, cur, P<int>(ctx->dflags), nxt, dnum,
-                                           ncur, st));
+      // the targets that are not yet converged, in list order (see k_sel_count)
+      const int nblk = cdiv(ncur, SEL_BLOCK);
+      k_sel_count<<<nblk, 64, 0, st>>>(ncur, P<int>(ctx->dflags), seloff);
+      k_sel_scan<<<1, 64, 0, st>>>(nblk, seloff, dnum);
       int left = 0;
       HIPCHK(hipMemcpyAsync(&left, dnum, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
+      if(left > 0)
+        {
+          k_sel_scatter<<<nblk, 64, 0, st>>>(ncur, cur, P<int>(ctx->dflags), seloff, nxt);
+          HIPCHK(hipGetLastError());
+        }
       ncur = left;
       int *tmp = cur;
       cur = nxt;
@@ -1059,6 +1130,11 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
             p->ComovingIntegrationOn, p->raw_dtentropy};
+  // Underneath a gravity pair the hydro kernel (128 VGPRs) only fits where an Ewald wavefront would
+  // sit, and while both walks run it slows them by more than it gains (11.4 vs 11.2 ms per step at
+  // c2): it starts when the Ewald walk has drained and fills the tail of the Newtonian walk instead.
+  if(ctx->grav_pending && !getenv("GHIP_HYDRO_EARLY"))
+    HIPCHK(hipStreamWaitEvent(st, ctx->evx[3], 0));
   HIPCHK(hipEventRecord(ctx->ev[10], st));
   const int nbk = (nt + 63) / 64;
   int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
