@@ -218,6 +218,60 @@ def test_newton_ewald_pair_equals_the_two_calls(subset):
     assert relerr(res[1][0][tg], oacc) < TOL
 
 
+@pytest.mark.parametrize("ng", [12, 48])
+def test_overlapped_step_equals_the_phase_by_phase_step(ng):
+    """The step as bench.py and the sharded driver issue it -- tree build, Newton+Ewald pair left in
+    flight, density / hmax / hydro enqueued underneath (second half of the gas-tree build deferred
+    into that shadow, one-wavefront workgroups, hydro held until the Ewald walk has drained) -- must
+    give what the same phases give when each is waited for.  ng = 48 is large enough for the pair
+    to cap the Newtonian walk's occupancy (>= 3072 buckets)."""
+    B = bindings()
+    pr = Problem(ng=ng, gas=True, periodic=1)
+    rng = np.random.default_rng(12)
+    old = 0.5 + rng.random(pr.n)
+    fields = (B.F_GRAVACCEL, B.F_GRAVCOST, B.F_OLDACC, B.F_HSML, B.F_NUMNGB, B.F_DENSITY,
+              B.F_DHSMLFAC, B.F_DIVVEL, B.F_CURLVEL, B.F_PRESSURE, B.F_HYDROACCEL, B.F_DTENTROPY,
+              B.F_MAXSIGNALVEL)
+    out = {}
+    for mode in ("phases", "overlapped", "overlapped"):
+        fp = pr.device()
+        fp.set_field(B.F_OLDACC, old)
+        for rep in range(2):                     # second repetition: adaptive plans are warm
+            pr.device_tree(fp)
+            if mode == "phases":
+                fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON)
+                fp.sync()
+                fp.gravity(pr.g_grav(0.0), B.WALK_EWALD)
+                fp.sync()
+                fp.density(pr.g_dens())
+                fp.sync()
+                fp.update_hmax()
+                fp.hydro(pr.g_hydro())
+                fp.sync()
+            else:
+                fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+                fp.density(pr.g_dens())
+                fp.update_hmax()
+                fp.hydro(pr.g_hydro())
+            if rep == 0:
+                fp.set_field(B.F_OLDACC, old)    # same inputs for the second repetition
+                fp.set_field(B.F_HSML, pr.hsml0)
+        fp.gravity_finish(pr.G)
+        res = [fp.get_field(f) for f in fields]
+        if mode in out:
+            for a, b in zip(out[mode], res):     # run-to-run: same launch shapes, same bits
+                assert np.array_equal(a, b)
+        out[mode] = res
+    for f, a, b in zip(fields, out["phases"], out["overlapped"]):
+        if f == B.F_GRAVCOST:
+            assert np.array_equal(a, b)
+        elif f in (B.F_GRAVACCEL, B.F_OLDACC):
+            # the per-bucket wavefront split of the walks may differ between the two sequences
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+        else:
+            assert np.array_equal(a, b), f       # the SPH phases do not depend on the walks at all
+
+
 def test_gravity_clustered_and_unequal_softenings():
     B = bindings()
     ic = ics.make_plummer(6000, gas_fraction=0.3)
