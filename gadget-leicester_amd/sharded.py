@@ -64,10 +64,14 @@ class ShardedForceStep:
             return
         group, allb, work, on_gpu = handle
         if work is not None:
-            work.wait()
+            work.wait()          # orders torch's current stream behind the collective
         if on_gpu:
+            # wait for that stream only: a device-wide synchronize would also wait for a gravity
+            # pair still in flight on the library's own streams and undo the overlap
             import torch
-            torch.cuda.synchronize()
+            done = torch.cuda.Event()
+            done.record()
+            done.synchronize()
         self.e.shard_unpack(group, allb.data_ptr(), self.world)
 
     def exchange(self, group):
