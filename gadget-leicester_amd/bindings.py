@@ -141,7 +141,8 @@ EXPORTS = [
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
-    "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft"]
+    "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
+    "ghip_gravity_vacuum_energy"]
 
 
 def lib():
@@ -171,6 +172,7 @@ def lib():
         L.ghip_gravity_ext_soft.argtypes = [vp, C.POINTER(GravParams), C.c_int, C.c_int, vp, vp, vp,
                                             vp, vp, vp]
         L.ghip_set_adaptive_gravsoft.argtypes = [vp, C.c_int]
+        L.ghip_gravity_vacuum_energy.argtypes = [vp, C.c_double]
         L.ghip_gravity_finish.argtypes = [vp, C.c_double]
         L.ghip_gravity_finish_all.argtypes = [vp, C.c_double]
         L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
@@ -324,6 +326,10 @@ class ForcePath:
 
     def gravity_finish_all(self, G):
         self._chk(self.L.ghip_gravity_finish_all(self.h, float(G)))
+
+    def gravity_vacuum_energy(self, fac):
+        """GravAccel += fac * Pos (gravtree.c:470-483), fac = OmegaLambda * Hubble^2."""
+        self._chk(self.L.ghip_gravity_vacuum_energy(self.h, float(fac)))
 
     def gravity_direct(self, params):
         self._chk(self.L.ghip_gravity_direct(self.h, C.byref(params)))

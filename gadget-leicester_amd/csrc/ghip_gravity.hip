@@ -26,6 +26,19 @@ __global__ void k_grav_finish(int nt, const int *__restrict__ tgt, const int *__
   oacc[2 * (size_t) n + i] = a2 * G;
 }
 
+// gravtree.c:470-483: GravAccel += OmegaLambda * Hubble^2 * Pos (vacuum energy in physical
+// coordinates; non-periodic, non-comoving runs without a PM mesh), after the multiplication by G
+__global__ void k_grav_vacuum(int nt, const int *__restrict__ tgt, const int *__restrict__ perm, int n,
+                              double fac, const double *__restrict__ pos, double *__restrict__ oacc)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  int i = perm[tgt[ti]];
+  for(int j = 0; j < 3; j++)
+    oacc[(size_t) j * n + i] += fac * pos[(size_t) j * n + i];
+}
+
 // softened direct summation (formula of forcetree.c:4273-4336), LDS-tiled, for accuracy checks
 __global__ void __launch_bounds__(256)
 k_grav_direct(int n, const double *__restrict__ sx, const double *__restrict__ sy,
@@ -722,6 +735,25 @@ extern "C" int ghip_gravity_finish_all(ghip_ctx *ctx, double G)
   k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
     nt, P<int>(ctx->tg_grav), P<int>(ctx->gt.perm), ctx->n, G,
     P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+extern "C" int ghip_gravity_vacuum_energy(ghip_ctx *ctx, double fac)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  if(!ctx)
+    return GHIP_EINVAL;
+  if(!ctx->gt.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_vacuum_energy: no tree");
+  GCHK(ghip_build_target_lists(ctx));
+  int nt = ctx->nt_grav;   // every active particle, like ghip_gravity_finish_all
+  if(nt == 0)
+    return GHIP_OK;
+  k_grav_vacuum<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
+    nt, P<int>(ctx->tg_grav), P<int>(ctx->gt.perm), ctx->n, fac, P<double>(ctx->f[GHIP_F_POS]),
+    P<double>(ctx->f[GHIP_F_GRAVACCEL]));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }

@@ -547,6 +547,11 @@ void gravity_tree(void)
     return;
   if(All.TypeOfOpeningCriterion == 1)
     All.ErrTolTheta = 0; /* gravtree.c:396-397 */
+  /* gravtree.c:470-483: vacuum energy in physical coordinates */
+  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn == 0)
+    if(chk(ghip_gravity_vacuum_energy(Ctx, All.OmegaLambda * All.Hubble * All.Hubble),
+           "ghip_gravity_vacuum_energy"))
+      return;
   ghip_layout lay;
   gadget_force_layout(&lay);
   if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))

@@ -296,6 +296,10 @@ int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
 int ghip_gravity_finish(ghip_ctx *ctx, double G);
 /* the same for ALL active particles regardless of the shard (multi-GPU: after the all-gather) */
 int ghip_gravity_finish_all(ghip_ctx *ctx, double G);
+/* GravAccel += fac * Pos for all active particles, fac = OmegaLambda * Hubble^2: the vacuum-energy
+ * term of runs in physical coordinates (gravtree.c:470-483, !PERIODIC && !PMGRID &&
+ * ComovingIntegrationOn == 0); call it after ghip_gravity_finish */
+int ghip_gravity_vacuum_energy(ghip_ctx *ctx, double fac);
 /* the same with gravdata_in.Soft (allvars.h:1695, gravtree.c:214-220): soft[a] = Hsml of a gas
  * target, used when ghip_set_adaptive_gravsoft is on; NULL = ghip_gravity_ext */
 int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,

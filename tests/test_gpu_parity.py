@@ -783,6 +783,26 @@ def test_force_treebuild_fills_the_hosts_tree_arrays():
     host.close()
 
 
+def test_gravity_tree_adds_the_vacuum_energy_term_in_physical_coordinates():
+    """gravtree.c:470-483: without PERIODIC and PMGRID and with ComovingIntegrationOn == 0,
+    gravity_tree() adds OmegaLambda * Hubble^2 * Pos after the multiplication by G; OldAcc is the
+    G-less tree acceleration's norm (gravtree.c:381-393), untouched by the term."""
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    pr = Problem(ng=8, gas=True, periodic=0)
+    host, P, S = _host_problem(pr, H, 0)
+    host.All.OmegaLambda, host.All.Hubble = 0.7, 3.0
+    host.L.gravity_tree()
+    assert host.endrun_codes == []
+    T = pr.oracle_tree()
+    oacc, ocost = T.gravity(pr.o_grav(pr.theta), _all(pr.n), np.zeros(pr.n))
+    want = pr.G * oacc + 0.7 * 9.0 * pr.ic["pos"]
+    assert np.abs(0.7 * 9.0 * pr.ic["pos"]).max() > 1e-3 * np.abs(pr.G * oacc).max()
+    assert np.abs(P["GravAccel"] - want).max() < TOL * np.abs(want).max()
+    assert relerr(P["OldAcc"], np.linalg.norm(oacc, axis=1)) < TOL
+    assert np.array_equal(P["GravCost"], ocost.astype(np.float32))
+    host.close()
+
+
 def test_per_target_evaluate_functions():
     """force_treeevaluate / density_evaluate / hydro_evaluate / ngb_treefind_* with the
     reference's signatures (forcetree.h:31-35, 107-111; proto.h:205, 229)."""
