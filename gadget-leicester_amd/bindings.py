@@ -64,7 +64,8 @@ class DriftParams(C.Structure):
                 ("ComovingIntegrationOn", C.c_int), ("logTimeBegin", C.c_double),
                 ("logTimeMax", C.c_double), ("DriftTable", C.c_void_p),
                 ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p),
-                ("MinGasHsml", C.c_double), ("box_wrap", C.c_int), ("BoxSize", C.c_double)]
+                ("MinGasHsml", C.c_double), ("box_wrap", C.c_int), ("BoxSize", C.c_double),
+                ("pmgrid", C.c_int)]
 
 
 class KickParams(C.Structure):
@@ -76,7 +77,17 @@ class KickParams(C.Structure):
                 ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint),
                 ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double),
                 ("GravKickTable", C.c_void_p), ("HydroKickTable", C.c_void_p),
-                ("AdaptiveGravsoftForGasHsml", C.c_int)]
+                ("AdaptiveGravsoftForGasHsml", C.c_int), ("pmgrid", C.c_int),
+                ("dt_gravkickB", C.c_double)]
+
+
+class PmKickParams(C.Structure):
+    """ghip_pmkick_params (the long-range kick ending a PM step, timestep.c:269-345)"""
+    _fields_ = [("Ti_Current", C.c_int), ("Timebase_interval", C.c_double),
+                ("ComovingIntegrationOn", C.c_int), ("logTimeBegin", C.c_double),
+                ("logTimeMax", C.c_double), ("GravKickTable", C.c_void_p),
+                ("HydroKickTable", C.c_void_p), ("dt_gravkick", C.c_double),
+                ("dt_gravkickB", C.c_double)]
 
 
 class PmParams(C.Structure):
@@ -142,7 +153,7 @@ EXPORTS = [
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
     "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
-    "ghip_gravity_vacuum_energy"]
+    "ghip_gravity_vacuum_energy", "ghip_pm_kick"]
 
 
 def lib():
@@ -173,6 +184,7 @@ def lib():
                                             vp, vp, vp]
         L.ghip_set_adaptive_gravsoft.argtypes = [vp, C.c_int]
         L.ghip_gravity_vacuum_energy.argtypes = [vp, C.c_double]
+        L.ghip_pm_kick.argtypes = [vp, C.POINTER(PmKickParams)]
         L.ghip_gravity_finish.argtypes = [vp, C.c_double]
         L.ghip_gravity_finish_all.argtypes = [vp, C.c_double]
         L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
@@ -335,8 +347,9 @@ class ForcePath:
         self._chk(self.L.ghip_gravity_direct(self.h, C.byref(params)))
 
     def drift(self, time1, timebase, min_gas_hsml=0.0, box_wrap=False, boxsize=1.0, tables=None,
-              log_time_begin=0.0, log_time_max=0.0):
+              log_time_begin=0.0, log_time_max=0.0, pmgrid=False):
         p = DriftParams()
+        p.pmgrid = int(bool(pmgrid))
         p.time1, p.Timebase_interval = int(time1), float(timebase)
         p.MinGasHsml, p.box_wrap, p.BoxSize = float(min_gas_hsml), int(box_wrap), float(boxsize)
         if tables is not None:
@@ -345,6 +358,19 @@ class ForcePath:
             p.logTimeBegin, p.logTimeMax = float(log_time_begin), float(log_time_max)
             p.DriftTable, p.GravKickTable, p.HydroKickTable = [t.ctypes.data for t in self._tabs]
         self._chk(self.L.ghip_drift(self.h, C.byref(p)))
+
+    def pm_kick(self, ti_current, timebase, dt_gravkick, dt_gravkickB, kick_tables=None,
+                log_time_begin=0.0, log_time_max=0.0):
+        """ghip_pm_kick: Vel += GravPM * dt_gravkick for every particle, VelPred of gas rebuilt."""
+        p = PmKickParams()
+        p.Ti_Current, p.Timebase_interval = int(ti_current), float(timebase)
+        p.dt_gravkick, p.dt_gravkickB = float(dt_gravkick), float(dt_gravkickB)
+        if kick_tables is not None:
+            self._pktabs = [np.ascontiguousarray(t, dtype=np.float64) for t in kick_tables]
+            p.ComovingIntegrationOn = 1
+            p.logTimeBegin, p.logTimeMax = float(log_time_begin), float(log_time_max)
+            p.GravKickTable, p.HydroKickTable = [t.ctypes.data for t in self._pktabs]
+        self._chk(self.L.ghip_pm_kick(self.h, C.byref(p)))
 
     def advance_timesteps(self, params, kick_tables=None):
         """ghip_advance_timesteps; returns (TimeBinCount[32], TimeBinCountSph[32]).  A timestep

@@ -15,6 +15,7 @@ __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
                         const double *__restrict__ vel, const int *__restrict__ type,
                         int *__restrict__ ti_current, const int *__restrict__ timebin,
                         const int *__restrict__ ti_begstep, const double *__restrict__ gravaccel,
+                        const double *__restrict__ gravpm,
                         double *__restrict__ velpred, const double *__restrict__ hydroaccel,
                         double *__restrict__ density, double *__restrict__ hsml,
                         const double *__restrict__ divvel, const double *__restrict__ entropy,
@@ -48,8 +49,13 @@ __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
       if(i < ngas && type[i] == 0)
         {
           for(int j = 0; j < 3; j++)
-            velpred[(size_t) j * ngas + i] += gravaccel[(size_t) j * n + i] * dt_gravkick +
-                                              hydroaccel[(size_t) j * ngas + i] * dt_hydrokick;
+            {
+              double g = gravaccel[(size_t) j * n + i];
+              if(gravpm)   // predict.c:181-184 (PMGRID)
+                g = g + gravpm[(size_t) j * n + i];
+              velpred[(size_t) j * ngas + i] +=
+                g * dt_gravkick + hydroaccel[(size_t) j * ngas + i] * dt_hydrokick;
+            }
           double dv = divvel[i];
           density[i] *= exp(-dv * dt_drift);
           double h = hsml[i] * exp(0.333333333333 * dv * dt_drift);
@@ -120,7 +126,9 @@ extern "C" int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p)
     n, ng, k, P<double>(ctx->f[GHIP_F_POS]), P<double>(ctx->f[GHIP_F_VEL]),
     P<int>(ctx->f[GHIP_F_TYPE]), P<int>(ctx->f[GHIP_F_TI_CURRENT]),
     P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TI_BEGSTEP]),
-    P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_VELPRED]),
+    P<double>(ctx->f[GHIP_F_GRAVACCEL]),
+    p->pmgrid ? P<double>(ctx->f[GHIP_F_GRAVPM]) : (const double *) nullptr,
+    P<double>(ctx->f[GHIP_F_VELPRED]),
     P<double>(ctx->f[GHIP_F_HYDROACCEL]), P<double>(ctx->f[GHIP_F_DENSITY]),
     P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_DIVVEL]),
     P<double>(ctx->f[GHIP_F_ENTROPY]), P<double>(ctx->f[GHIP_F_DTENTROPY]),

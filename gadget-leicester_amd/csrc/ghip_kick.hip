@@ -34,6 +34,8 @@ struct KickK
   double errtol, courant, maxdt, mindt, dtdisp;
   double soft[6];
   int adaptive_hsml;
+  int pmgrid;            // PMGRID: GravPM enters the criterion and VelPred (timestep.c:648-652, 511-513)
+  double dt_gravkickB;   // timestep.c:66-72
   double minegy;
   unsigned int active;
   DriftK tab;   // gravkick / hydrokick tables (comoving)
@@ -42,6 +44,7 @@ struct KickK
 __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n, int ngas, KickK k,
                                     const int *__restrict__ type, double *__restrict__ vel,
                                     const double *__restrict__ gravaccel,
+                                    const double *__restrict__ gravpm,
                                     const double *__restrict__ hydroaccel,
                                     double *__restrict__ velpred, double *__restrict__ entropy,
                                     double *__restrict__ dtentropy,
@@ -66,6 +69,15 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
 
   // ---- get_timestep, timestep.c:636-700, 947-1123 ----
   double ax = k.fac1 * g[0], ay = k.fac1 * g[1], az = k.fac1 * g[2];
+  double pm[3] = {0, 0, 0};
+  if(k.pmgrid)   // timestep.c:648-652
+    {
+      for(int j = 0; j < 3; j++)
+        pm[j] = gravpm[(size_t) j * n + i];
+      ax += k.fac1 * pm[0];
+      ay += k.fac1 * pm[1];
+      az += k.fac1 * pm[2];
+    }
   if(ty == 0)
     {
       ax += k.fac2 * hy[0];
@@ -162,7 +174,10 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
       for(int j = 0; j < 3; j++)
         {
           v[j] += hy[j] * dt_hydrokick;   // timestep.c:491-494
-          velpred[(size_t) j * ngas + i] = v[j] - dt_gravkick2 * g[j] - dt_hydrokick2 * hy[j];
+          double vp = v[j] - dt_gravkick2 * g[j] - dt_hydrokick2 * hy[j];
+          if(k.pmgrid)
+            vp += pm[j] * k.dt_gravkickB;   // timestep.c:511-513
+          velpred[(size_t) j * ngas + i] = vp;
         }
       double A = entropy[i], dA = dtentropy[i];
       if(dA * dt_entr > -0.5 * A)   // timestep.c:553-557
@@ -256,6 +271,8 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   for(int t = 0; t < 6; t++)
     k.soft[t] = p->SofteningTable[t];
   k.adaptive_hsml = p->AdaptiveGravsoftForGasHsml;
+  k.pmgrid = p->pmgrid;
+  k.dt_gravkickB = p->dt_gravkickB;
   k.minegy = p->MinEgySpec;
   k.active = p->TimeBinActive;
   k.tab.timebase = p->Timebase_interval;
@@ -281,7 +298,8 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   if(nact > 0)
     k_advance_timesteps<<<cdiv(nact, 256), 256, 0, st>>>(
       nact, act, n, ng, k, P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->f[GHIP_F_VEL]),
-      P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_HYDROACCEL]),
+      P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_GRAVPM]),
+      P<double>(ctx->f[GHIP_F_HYDROACCEL]),
       P<double>(ctx->f[GHIP_F_VELPRED]), P<double>(ctx->f[GHIP_F_ENTROPY]),
       P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_DENSITY]),
       P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]),
@@ -422,5 +440,86 @@ extern "C" int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_
       min_mass[t] = h[6 + t];
       count[t] = (long long) h[12 + t];
     }
+  return GHIP_OK;
+}
+
+// The long-range kick at the end of a PM step (timestep.c:269-345): every particle gets
+// Vel += GravPM * dt_gravkick; the predicted velocity of every gas particle is rebuilt from the new
+// Vel at the current time (its own step's mid-point kicks + the new PM half-step dt_gravkickB).
+__global__ void k_pm_kick(int n, int ngas, int ti_current, DriftK tab, double dt_gravkick,
+                          double dt_gravkickB, const int *__restrict__ type,
+                          const int *__restrict__ timebin, const int *__restrict__ ti_begstep,
+                          double *__restrict__ vel, const double *__restrict__ gravaccel,
+                          const double *__restrict__ gravpm, const double *__restrict__ hydroaccel,
+                          double *__restrict__ velpred)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  double pm[3], v[3];
+  for(int j = 0; j < 3; j++)
+    {
+      pm[j] = gravpm[(size_t) j * n + i];
+      v[j] = vel[(size_t) j * n + i] + pm[j] * dt_gravkick;   // timestep.c:313
+      vel[(size_t) j * n + i] = v[j];
+    }
+  if(type[i] == 0 && i < ngas)
+    {
+      const int tb = timebin[i];
+      const int dt_step = tb ? (1 << tb) : 0;   // timestep.c:317
+      const int t0 = ti_begstep[i];
+      double dt_gravkickA, dt_hydrokick;
+      if(tab.comoving)   // timestep.c:319-325
+        {
+          dt_gravkickA = d_table_factor(tab.gravkick, t0, ti_current, tab) -
+                         d_table_factor(tab.gravkick, t0, t0 + dt_step / 2, tab);
+          dt_hydrokick = d_table_factor(tab.hydrokick, t0, ti_current, tab) -
+                         d_table_factor(tab.hydrokick, t0, t0 + dt_step / 2, tab);
+        }
+      else
+        dt_gravkickA = dt_hydrokick = (ti_current - (t0 + dt_step / 2)) * tab.timebase;
+      for(int j = 0; j < 3; j++)   // timestep.c:330-333
+        velpred[(size_t) j * ngas + i] = v[j] + gravaccel[(size_t) j * n + i] * dt_gravkickA +
+                                         hydroaccel[(size_t) j * ngas + i] * dt_hydrokick +
+                                         pm[j] * dt_gravkickB;
+    }
+}
+
+extern "C" int ghip_pm_kick(ghip_ctx *ctx, const ghip_pmkick_params *p)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  if(!ctx || !p)
+    return GHIP_EINVAL;
+  if(p->ComovingIntegrationOn && (!p->GravKickTable || !p->HydroKickTable))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_pm_kick: comoving integration needs the kick tables");
+  const int n = ctx->n, ng = ctx->ngas;
+  if(n == 0)
+    return GHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DriftK tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.timebase = p->Timebase_interval;
+  tab.comoving = p->ComovingIntegrationOn;
+  tab.logTimeBegin = p->logTimeBegin;
+  tab.logTimeMax = p->logTimeMax;
+  if(p->ComovingIntegrationOn)
+    {
+      GCHK(ghip_ensure(ctx, ctx->stage, 3 * DRIFT_TABLE_LENGTH * 8));
+      double *d = P<double>(ctx->stage);
+      HIPCHK(hipMemcpyAsync(d + DRIFT_TABLE_LENGTH, p->GravKickTable, DRIFT_TABLE_LENGTH * 8,
+                            hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(d + 2 * DRIFT_TABLE_LENGTH, p->HydroKickTable, DRIFT_TABLE_LENGTH * 8,
+                            hipMemcpyHostToDevice, st));
+      tab.gravkick = d + DRIFT_TABLE_LENGTH;
+      tab.hydrokick = d + 2 * DRIFT_TABLE_LENGTH;
+    }
+  k_pm_kick<<<cdiv(n, 256), 256, 0, st>>>(
+    n, ng, p->Ti_Current, tab, p->dt_gravkick, p->dt_gravkickB, P<int>(ctx->f[GHIP_F_TYPE]),
+    P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TI_BEGSTEP]), P<double>(ctx->f[GHIP_F_VEL]),
+    P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_GRAVPM]),
+    P<double>(ctx->f[GHIP_F_HYDROACCEL]), P<double>(ctx->f[GHIP_F_VELPRED]));
+  HIPCHK(hipGetLastError());
   return GHIP_OK;
 }

@@ -138,6 +138,7 @@ typedef struct
   double MinGasHsml;
   int box_wrap;              /* also apply do_box_wrapping() with BoxSize */
   double BoxSize;
+  int pmgrid;                /* PMGRID: VelPred += (GravAccel + GravPM) * dt_gravkick (predict.c:181-184) */
 } ghip_drift_params;
 
 /* "next" row N1: timestep criterion + kick for the active particles
@@ -159,7 +160,25 @@ typedef struct
   const double *GravKickTable, *HydroKickTable;   /* host, 1000 entries each; comoving only */
   int AdaptiveGravsoftForGasHsml; /* ADAPTIVE_GRAVSOFT_FORGAS + _HSML: the gravity criterion of a
                                      gas particle uses Hsml/2.8 as its softening (timestep.c:740-743) */
+  int pmgrid;                /* PMGRID: GRAVPM is added to the acceleration of the gravity criterion
+                                (timestep.c:648-652) and VelPred += GravPM * dt_gravkickB (:511-513) */
+  double dt_gravkickB;       /* timestep.c:66-72, from All.PM_Ti_begstep / PM_Ti_endstep */
 } ghip_kick_params;
+
+/* the long-range kick that ends a PM step (timestep.c:269-345).  The integer-timeline bookkeeping
+ * (new PM step, All.PM_Ti_begstep/endstep, :273-300) stays with the host, which passes the two kick
+ * factors: dt_gravkick over [mid-point of the old PM step, mid-point of the new one] and the new
+ * dt_gravkickB (:296-300).  In/out VEL, VELPRED; in GRAVPM, GRAVACCEL, HYDROACCEL, TIMEBIN,
+ * TI_BEGSTEP, TYPE.  ALL particles are kicked, not the active list. */
+typedef struct
+{
+  int Ti_Current;
+  double Timebase_interval;
+  int ComovingIntegrationOn;
+  double logTimeBegin, logTimeMax;
+  const double *GravKickTable, *HydroKickTable;   /* host, 1000 entries each; comoving only */
+  double dt_gravkick, dt_gravkickB;
+} ghip_pmkick_params;
 
 /* "next" row N2: byte offsets of struct NODE / struct extNODE (allvars.h:1847-1916) as the host
  * was compiled; -1 = member absent / not wanted.  Vectors are 3 consecutive doubles. */
@@ -250,6 +269,7 @@ int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p);
 int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p, long long *TimeBinCount,
                            long long *TimeBinCountSph);
 int ghip_timestep_endrun_code(const ghip_ctx *ctx);
+int ghip_pm_kick(ghip_ctx *ctx, const ghip_pmkick_params *p);
 /* per-type sums of find_dt_displacement_constraint (timestep.c:1140-1156): sum of |v|^2, smallest
  * positive mass (1e30 if none), particle count -- 6 entries each */
 int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_mass[6], long long count[6]);

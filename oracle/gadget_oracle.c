@@ -1703,6 +1703,20 @@ int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
               const double *hydroaccel, double *density, double *hsml, const double *divvel,
               const double *entropy, const double *dtentropy, double *pressure)
 {
+  return orc_drift_pm(n, ngas, time1, timebase, tables, logTimeBegin, logTimeMax, minhsml, wrap,
+                      boxsize, pos, vel, type, ti_current, timebin, ti_begstep, gravaccel, NULL,
+                      velpred, hydroaccel, density, hsml, divvel, entropy, dtentropy, pressure);
+}
+
+/* gravpm != NULL: PMGRID, VelPred += (GravAccel + GravPM) * dt_gravkick (predict.c:181-184) */
+int orc_drift_pm(int n, int ngas, int time1, double timebase, const double *tables,
+                 double logTimeBegin, double logTimeMax, double minhsml, int wrap, double boxsize,
+                 double *pos, const double *vel, const int *type, int *ti_current,
+                 const int *timebin, const int *ti_begstep, const double *gravaccel,
+                 const double *gravpm, double *velpred, const double *hydroaccel, double *density,
+                 double *hsml, const double *divvel, const double *entropy, const double *dtentropy,
+                 double *pressure)
+{
   for(int i = 0; i < n; i++)
     {
       int time0 = ti_current[i];
@@ -1726,8 +1740,12 @@ int orc_drift(int n, int ngas, int time1, double timebase, const double *tables,
           if(i < ngas && type[i] == 0)
             {
               for(int j = 0; j < 3; j++)
-                velpred[3 * i + j] += gravaccel[3 * i + j] * dt_gravkick +
-                  hydroaccel[3 * i + j] * dt_hydrokick;
+                {
+                  double g = gravaccel[3 * i + j];
+                  if(gravpm)
+                    g = g + gravpm[3 * i + j];
+                  velpred[3 * i + j] += g * dt_gravkick + hydroaccel[3 * i + j] * dt_hydrokick;
+                }
               density[i] *= exp(-divvel[i] * dt_drift);
               hsml[i] *= exp(0.333333333333 * divvel[i] * dt_drift);
               if(hsml[i] < minhsml)
@@ -1855,6 +1873,12 @@ int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive
       /* ---- get_timestep ---- */
       double ax = fac1 * gravaccel[3 * i], ay = fac1 * gravaccel[3 * i + 1],
              az = fac1 * gravaccel[3 * i + 2];
+      if(p->pmgrid) /* timestep.c:648-652 */
+        {
+          ax += fac1 * p->gravpm[3 * i];
+          ay += fac1 * p->gravpm[3 * i + 1];
+          az += fac1 * p->gravpm[3 * i + 2];
+        }
       if(type[i] == 0)
         {
           ax += fac2 * hydroaccel[3 * i];
@@ -1955,6 +1979,8 @@ int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive
               vel[3 * i + j] += hydroaccel[3 * i + j] * dt_hydrokick;
               velpred[3 * i + j] = vel[3 * i + j] - dt_gravkick2 * gravaccel[3 * i + j] -
                                    dt_hydrokick2 * hydroaccel[3 * i + j];
+              if(p->pmgrid) /* timestep.c:511-513 */
+                velpred[3 * i + j] += p->gravpm[3 * i + j] * p->dt_gravkickB;
             }
           /* timestep.c:553-557 (DO_NOT_PROTECT off) */
           if(dtentropy[i] * dt_entr > -0.5 * entropy[i])
@@ -1988,4 +2014,44 @@ int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive
     }
   (void) ngas;
   return err;
+}
+
+/* the long-range kick ending a PM step (timestep.c:301-345): all particles, not the active list.
+ * tables as in orc_drift (NULL when not comoving); dt_gravkick / dt_gravkickB from the caller's
+ * PM-step bookkeeping (timestep.c:273-300). */
+void orc_pm_kick(int n, int ngas, int ti_current, double timebase, const double *tables,
+                 double logTimeBegin, double logTimeMax, double dt_gravkick, double dt_gravkickB,
+                 const int *type, const int *timebin, const int *ti_begstep, double *vel,
+                 const double *gravaccel, const double *gravpm, const double *hydroaccel,
+                 double *velpred)
+{
+  for(int i = 0; i < n; i++)
+    {
+      for(int j = 0; j < 3; j++)
+        vel[3 * i + j] += gravpm[3 * i + j] * dt_gravkick;
+      if(type[i] == 0 && i < ngas)
+        {
+          int dt_step = (timebin[i] ? (1 << timebin[i]) : 0);
+          double dt_gravkickA, dt_hydrokick;
+          if(tables)
+            {
+              dt_gravkickA =
+                table_factor(tables + 1000, ti_begstep[i], ti_current, timebase, logTimeBegin,
+                             logTimeMax) -
+                table_factor(tables + 1000, ti_begstep[i], ti_begstep[i] + dt_step / 2, timebase,
+                             logTimeBegin, logTimeMax);
+              dt_hydrokick =
+                table_factor(tables + 2000, ti_begstep[i], ti_current, timebase, logTimeBegin,
+                             logTimeMax) -
+                table_factor(tables + 2000, ti_begstep[i], ti_begstep[i] + dt_step / 2, timebase,
+                             logTimeBegin, logTimeMax);
+            }
+          else
+            dt_gravkickA = dt_hydrokick = (ti_current - (ti_begstep[i] + dt_step / 2)) * timebase;
+          for(int j = 0; j < 3; j++)
+            velpred[3 * i + j] = vel[3 * i + j] + gravaccel[3 * i + j] * dt_gravkickA +
+                                 hydroaccel[3 * i + j] * dt_hydrokick +
+                                 gravpm[3 * i + j] * dt_gravkickB;
+        }
+    }
 }

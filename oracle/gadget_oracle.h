@@ -176,6 +176,9 @@ typedef struct
   const double *tables;       /* [3][1000] drift, gravkick, hydrokick */
   double logTimeBegin, logTimeMax;
   int AdaptiveGravsoftForGasHsml; /* ADAPTIVE_GRAVSOFT_FORGAS(_HSML): timestep.c:740-743 */
+  int pmgrid;                     /* PMGRID: timestep.c:648-652, 511-513 */
+  double dt_gravkickB;            /* timestep.c:66-72 */
+  const double *gravpm;           /* [n][3], PMGRID only */
 } orc_kick_params;
 
 void orc_velocity_moments(int n, const double *vel, const double *mass, const int *type,
@@ -184,6 +187,18 @@ double orc_dt_displacement(const double v2[6], const double minmass[6], const lo
                            int comoving, double hfac, double MaxSizeTimestep,
                            double MaxRMSDisplacementFac, double Omega0, double OmegaBaryon,
                            double Hubble, double G, int StarformationOn);
+int orc_drift_pm(int n, int ngas, int time1, double timebase, const double *tables,
+                 double logTimeBegin, double logTimeMax, double minhsml, int wrap, double boxsize,
+                 double *pos, const double *vel, const int *type, int *ti_current,
+                 const int *timebin, const int *ti_begstep, const double *gravaccel,
+                 const double *gravpm, double *velpred, const double *hydroaccel, double *density,
+                 double *hsml, const double *divvel, const double *entropy, const double *dtentropy,
+                 double *pressure);
+void orc_pm_kick(int n, int ngas, int ti_current, double timebase, const double *tables,
+                 double logTimeBegin, double logTimeMax, double dt_gravkick, double dt_gravkickB,
+                 const int *type, const int *timebin, const int *ti_begstep, double *vel,
+                 const double *gravaccel, const double *gravpm, const double *hydroaccel,
+                 double *velpred);
 int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive, const int *active,
                           const int *type, double *vel, const double *gravaccel,
                           const double *hydroaccel, double *velpred, double *entropy,

@@ -329,20 +329,21 @@ def gravity_direct_psoft(pos, mass, psoft, targets, periodic=False, boxsize=1.0,
 
 def drift(time1, timebase, pos, vel, ptype, ti_current, timebin, ti_begstep, gravaccel, velpred,
           hydroaccel, density, hsml, divvel, entropy, dtentropy, pressure, minhsml=0.0, wrap=False,
-          boxsize=1.0, tables=None, log_time_begin=0.0, log_time_max=0.0):
-    """In-place drift of copies; returns dict of the updated arrays."""
+          boxsize=1.0, tables=None, log_time_begin=0.0, log_time_max=0.0, gravpm=None):
+    """In-place drift of copies; returns dict of the updated arrays.  gravpm: PMGRID."""
     n, ngas = len(pos), len(velpred)
     out = dict(pos=_f64(pos).copy(), ti_current=_i32(ti_current).copy(),
                velpred=_f64(velpred).copy(), density=_f64(density).copy(), hsml=_f64(hsml).copy(),
                pressure=_f64(pressure).copy())
     tabs = None if tables is None else _f64(np.concatenate([np.ravel(t) for t in tables]))
     L = lib()
-    L.orc_drift.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double,
-                            C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 15
-    rc = L.orc_drift(n, ngas, int(time1), float(timebase), _p(tabs), float(log_time_begin),
+    L.orc_drift_pm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double,
+                               C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 16
+    pm = None if gravpm is None else _f64(gravpm)
+    rc = L.orc_drift_pm(n, ngas, int(time1), float(timebase), _p(tabs), float(log_time_begin),
                      float(log_time_max), float(minhsml), int(wrap), float(boxsize),
                      _p(out["pos"]), _p(_f64(vel)), _p(_i32(ptype)), _p(out["ti_current"]),
-                     _p(_i32(timebin)), _p(_i32(ti_begstep)), _p(_f64(gravaccel)),
+                     _p(_i32(timebin)), _p(_i32(ti_begstep)), _p(_f64(gravaccel)), _p(pm),
                      _p(out["velpred"]), _p(_f64(hydroaccel)), _p(out["density"]), _p(out["hsml"]),
                      _p(_f64(divvel)), _p(_f64(entropy)), _p(_f64(dtentropy)), _p(out["pressure"]))
     out["rc"] = rc
@@ -358,7 +359,8 @@ class KickParams(C.Structure):
                 ("dt_displacement", C.c_double), ("SofteningTable", C.c_double * 6),
                 ("MinEgySpec", C.c_double), ("TimeBinActive", C.c_uint), ("tables", C.c_void_p),
                 ("logTimeBegin", C.c_double), ("logTimeMax", C.c_double),
-                ("AdaptiveGravsoftForGasHsml", C.c_int)]
+                ("AdaptiveGravsoftForGasHsml", C.c_int), ("pmgrid", C.c_int),
+                ("dt_gravkickB", C.c_double), ("gravpm", C.c_void_p)]
 
 
 def velocity_moments(vel, mass, ptype):
@@ -387,7 +389,7 @@ def dt_displacement(v2, minmass, count, comoving, hfac, max_size_timestep, max_r
 
 def advance_timesteps(params, ptype, vel, gravaccel, hydroaccel, velpred, entropy, dtentropy,
                       density, pressure, hsml, maxsignalvel, timebin, ti_begstep, active=None,
-                      tables=None):
+                      tables=None, gravpm=None):
     """advance_and_find_timesteps + get_timestep + do_the_kick on copies; returns the updated
     arrays, the bin counts and rc (0 or the reference's endrun code)."""
     n, ngas = len(ptype), len(entropy)
@@ -398,6 +400,10 @@ def advance_timesteps(params, ptype, vel, gravaccel, hydroaccel, velpred, entrop
     if tables is not None:
         tabs = _f64(np.concatenate([np.ravel(t) for t in tables]))
         params.tables = tabs.ctypes.data
+    pm = None
+    if gravpm is not None:          # PMGRID (params.pmgrid / dt_gravkickB set by the caller)
+        pm = _f64(gravpm)
+        params.gravpm = pm.ctypes.data
     cnt = np.zeros(32, np.int64)
     sph = np.zeros(32, np.int64)
     act = None if active is None else _i32(active)
@@ -410,6 +416,24 @@ def advance_timesteps(params, ptype, vel, gravaccel, hydroaccel, velpred, entrop
                                  _p(_f64(hsml)), _p(_f64(maxsignalvel)), _p(out["timebin"]),
                                  _p(out["ti_begstep"]), _p(cnt), _p(sph))
     out.update(rc=rc, bincount=cnt, bincount_sph=sph)
+    return out
+
+
+def pm_kick(ti_current, timebase, dt_gravkick, dt_gravkickB, ptype, timebin, ti_begstep, vel,
+            gravaccel, gravpm, hydroaccel, velpred, tables=None, log_time_begin=0.0,
+            log_time_max=0.0):
+    """The long-range kick ending a PM step (timestep.c:301-345) on copies; returns vel, velpred."""
+    n, ngas = len(ptype), len(velpred)
+    out = dict(vel=_f64(vel).copy(), velpred=_f64(velpred).copy())
+    tabs = None if tables is None else _f64(np.concatenate([np.ravel(t) for t in tables]))
+    L = lib()
+    L.orc_pm_kick.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double,
+                              C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 8
+    L.orc_pm_kick.restype = None
+    L.orc_pm_kick(n, ngas, int(ti_current), float(timebase), _p(tabs), float(log_time_begin),
+                  float(log_time_max), float(dt_gravkick), float(dt_gravkickB), _p(_i32(ptype)),
+                  _p(_i32(timebin)), _p(_i32(ti_begstep)), _p(out["vel"]), _p(_f64(gravaccel)),
+                  _p(_f64(gravpm)), _p(_f64(hydroaccel)), _p(out["velpred"]))
     return out
 
 

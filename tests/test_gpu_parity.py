@@ -937,13 +937,15 @@ def test_shard_pack_unpack_reproduces_the_unsharded_step():
 # pre-condition of the path: drift (predict.c:129-259) and box wrapping (predict.c:282-310)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("comoving", [False, True])
-def test_drift_parity(comoving):
+@pytest.mark.parametrize("pmgrid", [False, True])
+def test_drift_parity(comoving, pmgrid):
     B = bindings()
     pr = Problem(ng=10, gas=True, periodic=1)
     rng = np.random.default_rng(21)
     n, ng = pr.n, pr.ngas
     ti_cur = rng.integers(0, 3, n).astype(np.int32)          # lazily drifted: mixed time0
     grav = rng.standard_normal((n, 3))
+    gpm = rng.standard_normal((n, 3))                        # PMGRID: predict.c:181-184
     hyd = rng.standard_normal((ng, 3))
     dens = 1.0 + rng.random(ng)
     divv = rng.standard_normal(ng)
@@ -960,13 +962,15 @@ def test_drift_parity(comoving):
     hfull[:ng] = hs
     for fid, arr in ((B.F_TI_CURRENT, ti_cur), (B.F_GRAVACCEL, grav), (B.F_HYDROACCEL, hyd),
                      (B.F_DENSITY, dens), (B.F_DIVVEL, divv), (B.F_PRESSURE, pres),
-                     (B.F_HSML, hfull)):
+                     (B.F_HSML, hfull), (B.F_GRAVPM, gpm)):
         fp.set_field(fid, arr)
     minh = float(np.median(hs))
-    fp.drift(7, pr.timebase * 50, min_gas_hsml=minh, box_wrap=True, boxsize=pr.box, **kw)
+    fp.drift(7, pr.timebase * 50, min_gas_hsml=minh, box_wrap=True, boxsize=pr.box, pmgrid=pmgrid,
+             **kw)
     want = O.drift(7, pr.timebase * 50, pr.ic["pos"], pr.ic["vel"], pr.ic["type"], ti_cur,
                    pr.timebin, pr.ti_begstep, grav, pr.velpred, hyd, dens, hs, divv, pr.entropy,
-                   pr.dtentropy, pres, minhsml=minh, wrap=True, boxsize=pr.box, **kw)
+                   pr.dtentropy, pres, minhsml=minh, wrap=True, boxsize=pr.box,
+                   gravpm=gpm if pmgrid else None, **kw)
     assert want["rc"] == 0
     assert np.array_equal(fp.get_field(B.F_TI_CURRENT), want["ti_current"])
     assert np.abs(fp.get_field(B.F_POS) - want["pos"]).max() < 1e-15
@@ -1035,6 +1039,12 @@ def test_timestep_and_kick_parity(comoving, subset, adaptive):
     n, ng = pr.n, pr.ngas
     st, par, tabs = _kick_case(pr, comoving)
     par["AdaptiveGravsoftForGasHsml"] = adaptive
+    # the adaptive variant also runs as a PMGRID build: GravPM in the criterion (timestep.c:648-652)
+    # and VelPred += GravPM * dt_gravkickB (:511-513)
+    gpm = None
+    if adaptive:
+        gpm = 3.0 * np.random.default_rng(77).standard_normal((n, 3))
+        par["pmgrid"], par["dt_gravkickB"] = 1, 0.00137
     soft = pr.force_soft / 2.8
     fp = pr.device()
     hfull = pr.hsml0.copy()
@@ -1045,6 +1055,8 @@ def test_timestep_and_kick_parity(comoving, subset, adaptive):
                      (B.F_DTENTROPY, st["dtentropy"]), (B.F_TIMEBIN, st["timebin"]),
                      (B.F_TI_BEGSTEP, st["ti_begstep"])):
         fp.set_field(fid, arr)
+    if gpm is not None:
+        fp.set_field(B.F_GRAVPM, gpm)
     active = None
     if subset:
         active = np.sort(np.random.default_rng(5).choice(n, n // 3, replace=False)).astype(np.int32)
@@ -1054,7 +1066,7 @@ def test_timestep_and_kick_parity(comoving, subset, adaptive):
     want = O.advance_timesteps(_fill(O.KickParams(), par, soft), pr.ic["type"], pr.ic["vel"],
                                st["grav"], st["hyd"], pr.velpred, st["entropy"], st["dtentropy"],
                                st["dens"], st["pres"], st["hs"], st["vsig"], st["timebin"],
-                               st["ti_begstep"], active=active, tables=tabs)
+                               st["ti_begstep"], active=active, tables=tabs, gravpm=gpm)
     assert want["rc"] == 0
     assert np.array_equal(fp.get_field(B.F_TIMEBIN), want["timebin"])
     assert np.array_equal(fp.get_field(B.F_TI_BEGSTEP), want["ti_begstep"])
@@ -1078,6 +1090,33 @@ def test_timestep_and_kick_parity(comoving, subset, adaptive):
         assert np.array_equal(fp.get_field(B.F_VEL)[rest], pr.ic["vel"][rest])
         assert np.array_equal(fp.get_field(B.F_TIMEBIN)[rest], st["timebin"][rest])
     assert fp.stats()["ms_kick"] > 0
+
+
+@pytest.mark.parametrize("comoving", [False, True])
+def test_pm_long_range_kick_parity(comoving):
+    """The kick that ends a PM step (timestep.c:301-345): Vel += GravPM * dt_gravkick for EVERY
+    particle and the predicted velocities of the gas rebuilt at the current time -- bit for bit."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    st, par, tabs = _kick_case(pr, comoving)
+    gpm = 2.0 * np.random.default_rng(78).standard_normal((n, 3))
+    fp = pr.device()
+    for fid, arr in ((B.F_GRAVACCEL, st["grav"]), (B.F_HYDROACCEL, st["hyd"]), (B.F_GRAVPM, gpm),
+                     (B.F_TIMEBIN, st["timebin"]), (B.F_TI_BEGSTEP, st["ti_begstep"])):
+        fp.set_field(fid, arr)
+    ti = par["Ti_Current"]
+    kw = {}
+    if comoving:
+        kw = dict(log_time_begin=par["logTimeBegin"], log_time_max=par["logTimeMax"])
+    fp.pm_kick(ti, par["Timebase_interval"], 0.0123, -0.0045,
+               kick_tables=None if tabs is None else tabs[1:], **kw)
+    want = O.pm_kick(ti, par["Timebase_interval"], 0.0123, -0.0045, pr.ic["type"], st["timebin"],
+                     st["ti_begstep"], pr.ic["vel"], st["grav"], gpm, st["hyd"], pr.velpred,
+                     tables=tabs, **kw)
+    assert np.array_equal(fp.get_field(B.F_VEL), want["vel"])
+    assert np.array_equal(fp.get_field(B.F_VELPRED), want["velpred"])
+    assert np.abs(want["vel"] - pr.ic["vel"]).max() > 0
 
 
 def test_advance_and_find_timesteps_on_aos_records():
