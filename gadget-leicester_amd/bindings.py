@@ -36,7 +36,7 @@ class Layout(C.Structure):
         "p_ti_begstep", "p_type", "p_timebin", "p_hsml", "p_numngb",
         "s_stride", "s_entropy", "s_pressure", "s_velpred", "s_maxsignalvel", "s_density",
         "s_dtentropy", "s_hydroaccel", "s_dhsmlfac", "s_divvel", "s_curlvel", "s_hsml",
-        "s_numngb", "p_ti_current")]
+        "s_numngb", "p_ti_current", "p_gravpm")]
 
 
 class GravParams(C.Structure):

@@ -455,6 +455,7 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
     k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
       n, (const char *) ip, lay->p_stride, lay->p_ti_current, P<int>(ctx->f[GHIP_F_TI_CURRENT]));
   UNPACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
+  UNPACK64(n, ip, lay->p_stride, lay->p_gravpm, 3, GHIP_F_GRAVPM);
   if(lay->p_hsml >= 0)
     UNPACK64(n, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
   if(ng > 0)
@@ -500,6 +501,7 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
     {
       PACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
       PACK64(n, ip, lay->p_stride, lay->p_oldacc, 1, GHIP_F_OLDACC);
+      PACK64(n, ip, lay->p_stride, lay->p_gravpm, 3, GHIP_F_GRAVPM);
       if(lay->p_gravcost >= 0)
         k_pack_cost_f32<<<cdiv((long long) n, 256), 256, 0, st>>>(
           n, (char *) ip, lay->p_stride, lay->p_gravcost, P<int>(ctx->f[GHIP_F_GRAVCOST]));

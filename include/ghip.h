@@ -84,6 +84,8 @@ typedef struct
   int s_hydroaccel, s_dhsmlfac, s_divvel, s_curlvel;
   int s_hsml, s_numngb; /* when PPP == SphP, else -1 */
   int p_ti_current;     /* i32 */
+  int p_gravpm;         /* P[].GravPM (PMGRID builds, allvars.h:1180-1183): uploaded with the records
+                           and written back with the gravity results; -1 otherwise */
 } ghip_layout;
 
 typedef struct

@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_reference_minimal_flag_set():
     H.lib().gadget_force_layout(C.byref(lay))
     want_p = dict(p_stride=112, p_pos=0, p_vel=24, p_mass=48, p_gravaccel=64, p_oldacc=88,
                   p_gravcost=96, p_ti_begstep=100, p_type=108, p_timebin=110, p_hsml=-1,
-                  p_numngb=-1, p_ti_current=104)
+                  p_numngb=-1, p_ti_current=104, p_gravpm=-1)
     want_s = dict(s_stride=184, s_entropy=0, s_pressure=8, s_velpred=16, s_maxsignalvel=40,
                   s_density=48, s_dtentropy=56, s_hydroaccel=64, s_dhsmlfac=88, s_divvel=96,
                   s_curlvel=104)

@@ -734,6 +734,44 @@ def test_compute_accelerations_sequence_on_aos_records():
     host.close()
 
 
+def test_pmgrid_records_carry_gravpm_through_the_offsets_table():
+    """A PMGRID build's struct particle_data is 136 bytes with GravPM[3] behind GravAccel
+    (allvars.h:1180-1183).  The library only sees byte offsets: GravPM is uploaded
+    with the records (a host-side long-range force feeds the device's kick and drift) and written
+    back with the gravity results (the device-side ghip_pm_periodic feeds the host)."""
+    B = bindings()
+    pr = Problem(ng=8, gas=False, periodic=1)
+    n = pr.n
+    pdt = np.dtype({"names": ["Pos", "Vel", "Mass", "ID", "GravAccel", "GravPM", "OldAcc",
+                              "GravCost", "Ti_begstep", "Ti_current", "Type", "TimeBin"],
+                    "formats": [("f8", 3), ("f8", 3), "f8", "u4", ("f8", 3), ("f8", 3), "f8", "f4",
+                                "i4", "i4", "i2", "i2"],
+                    "offsets": [0, 24, 48, 56, 64, 88, 112, 120, 124, 128, 132, 134],
+                    "itemsize": 136})
+    P = np.zeros(n, pdt)
+    P["Pos"], P["Vel"], P["Mass"], P["Type"] = pr.ic["pos"], pr.ic["vel"], pr.ic["mass"], pr.ic["type"]
+    rng = np.random.default_rng(4)
+    P["GravPM"] = rng.standard_normal((n, 3))
+    lay = B.Layout()
+    C.memset(C.byref(lay), 0xff, C.sizeof(lay))
+    lay.p_stride = 136
+    for name, key in (("Pos", "p_pos"), ("Vel", "p_vel"), ("Mass", "p_mass"),
+                      ("GravAccel", "p_gravaccel"), ("GravPM", "p_gravpm"), ("OldAcc", "p_oldacc"),
+                      ("GravCost", "p_gravcost"), ("Ti_begstep", "p_ti_begstep"),
+                      ("Ti_current", "p_ti_current"), ("Type", "p_type"), ("TimeBin", "p_timebin")):
+        setattr(lay, key, pdt.fields[name][1])
+    fp = B.ForcePath(0)
+    fp.upload_aos(P, None, lay)
+    assert np.array_equal(fp.get_field(B.F_GRAVPM), P["GravPM"])       # host -> device
+    fp.pm_periodic(16, pr.box, pr.G)                                   # device-side long-range force
+    want = fp.get_field(B.F_GRAVPM)
+    assert np.abs(want).max() > 0 and not np.array_equal(want, P["GravPM"])
+    ident = P["ID"].copy()
+    fp.download_aos(P, None, lay, gravity=True, density=False, hydro=False)
+    assert np.array_equal(P["GravPM"], want)                           # device -> host
+    assert np.array_equal(P["ID"], ident) and np.array_equal(P["Pos"], pr.ic["pos"])
+
+
 def test_force_treebuild_fills_the_hosts_tree_arrays():
     """force_treebuild() with Nodes_base/Extnodes_base/Nextnode/Father set ("next" row N2): a plain
     host-side Barnes-Hut walk over the exported arrays (the loop of force_treeevaluate,
