@@ -1157,6 +1157,95 @@ def test_pm_long_range_kick_parity(comoving):
     assert np.abs(want["vel"] - pr.ic["vel"]).max() > 0
 
 
+def test_resident_integration_loop_matches_the_oracle_loop():
+    """What row N1 is for: the particle state never leaves HBM between steps.  Three steps of
+    run.c's loop -- drift to the sync point, tree build, Newtonian + Ewald walks, density, hmax,
+    hydro, timestep + kick -- on the resident fields, against the same loop composed of the oracle's
+    restatements.  MaxSizeTimestep binds, so every particle shares one bin and is active in every
+    step; after three force computations positions agree to rounding and the kicked quantities to
+    the summation-order tolerance of the forces."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng, box = pr.n, pr.ngas, pr.box
+    typ, mass = pr.ic["type"], pr.ic["mass"]
+    bin_, tb = 20, 1.0e-3 / (1 << 20)
+    pr.timebase = tb
+    soft = pr.force_soft / 2.8
+    par = dict(Timebase_interval=tb, ComovingIntegrationOn=0, Time=1.0, hubble_a=1.0,
+               ErrTolIntAccuracy=1.0e3, CourantFac=1.0e3, MaxSizeTimestep=1.0e-3,
+               MinSizeTimestep=0.0, dt_displacement=1.0, MinEgySpec=0.0,
+               TimeBinActive=0xffffffff, logTimeBegin=0.0, logTimeMax=0.0)
+    tab = O.ewald_table(box)
+    zero_i = np.zeros(n, np.int32)
+    # ---- device state ----
+    fp = pr.device()
+    for fid in (B.F_TIMEBIN, B.F_TI_BEGSTEP, B.F_TI_CURRENT):
+        fp.set_field(fid, zero_i)
+    fp.set_field(B.F_OLDACC, np.zeros(n))
+    # ---- oracle state ----
+    o = dict(pos=pr.ic["pos"].copy(), vel=pr.ic["vel"].copy(), velpred=pr.velpred.copy(),
+             entropy=pr.entropy.copy(), dtentropy=pr.dtentropy.copy(), hsml=pr.hsml0.copy(),
+             timebin=zero_i.copy(), ti_begstep=zero_i.copy(), ti_current=zero_i.copy(),
+             oldacc=np.zeros(n), grav=np.zeros((n, 3)), hyd=np.zeros((ng, 3)),
+             density=np.ones(ng), divvel=np.zeros(ng), pressure=np.zeros(ng))
+    gas = _all(ng)
+    for step, ti in enumerate((0, 1 << bin_, 2 << bin_)):
+        pr.ti_current = ti
+        theta = pr.theta if step == 0 else 0.0           # accel.c:61-68: first pass Barnes-Hut
+        # -- oracle: drift_particle for everybody (run.c find_next_sync_point_and_drift) --
+        d = O.drift(ti, tb, o["pos"], o["vel"], typ, o["ti_current"], o["timebin"],
+                    o["ti_begstep"], o["grav"], o["velpred"], o["hyd"], o["density"],
+                    o["hsml"][:ng], o["divvel"], o["entropy"], o["dtentropy"], o["pressure"],
+                    wrap=True, boxsize=box)
+        assert d["rc"] == 0
+        o["pos"], o["ti_current"], o["velpred"] = d["pos"], d["ti_current"], d["velpred"]
+        o["hsml"][:ng] = d["hsml"]
+        extent = O.domain_extent(o["pos"])
+        T = O.Tree(o["pos"], o["vel"], mass, typ, pr.force_soft, hsml=o["hsml"], extent=extent)
+        acc, cost = T.gravity(pr.o_grav(theta), _all(n), o["oldacc"])
+        T.gravity_ewald_add(pr.o_grav(theta), tab, _all(n), o["oldacc"], acc, cost)
+        o["oldacc"] = np.linalg.norm(acc, axis=1)
+        o["grav"] = pr.G * acc
+        od = T.density(pr.o_dens(), gas, o["velpred"], o["entropy"], o["dtentropy"], o["timebin"],
+                       o["ti_begstep"], o["hsml"])
+        T.update_hmax(gas, od["hsml"], od["divvel"])
+        oh = T.hydro(pr.o_hydro(), gas, o["velpred"], od["hsml"], od["density"], od["pressure"],
+                     od["dhsmlfac"], od["divvel"], od["curlvel"], o["timebin"])
+        o["hsml"] = od["hsml"]
+        o["density"], o["divvel"] = od["density"][:ng], od["divvel"][:ng]
+        o["pressure"] = od["pressure"][:ng]
+        o["hyd"], o["dtentropy"] = oh["hydroaccel"][:ng], oh["dtentropy"][:ng]
+        par["Ti_Current"] = ti
+        k = O.advance_timesteps(_fill(O.KickParams(), par, soft), typ, o["vel"], o["grav"],
+                                o["hyd"], o["velpred"], o["entropy"], o["dtentropy"],
+                                o["density"], o["pressure"], o["hsml"][:ng],
+                                oh["maxsignalvel"][:ng], o["timebin"], o["ti_begstep"])
+        assert k["rc"] == 0 and np.all(k["timebin"] == bin_)
+        for key in ("vel", "velpred", "entropy", "dtentropy", "timebin", "ti_begstep"):
+            o[key] = k[key]
+        # -- device: the same phases on the resident fields, nothing uploaded in between --
+        fp.drift(ti, tb, box_wrap=True, boxsize=box)
+        fp.tree_build(extent[0], extent[1], extent[2], pr.force_soft)
+        fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD)
+        fp.density(pr.g_dens())
+        fp.update_hmax()
+        fp.hydro(pr.g_hydro())
+        fp.gravity_finish(pr.G)
+        fp.advance_timesteps(_fill(B.KickParams(), par, soft))
+    assert np.abs(fp.get_field(B.F_POS) - o["pos"]).max() < 1e-13
+    assert np.array_equal(fp.get_field(B.F_TIMEBIN), o["timebin"])
+    assert np.array_equal(fp.get_field(B.F_TI_BEGSTEP), o["ti_begstep"])
+    assert np.array_equal(fp.get_field(B.F_TI_CURRENT), o["ti_current"])
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), cost)
+    for fid, want in ((B.F_VEL, o["vel"]), (B.F_VELPRED, o["velpred"]), (B.F_GRAVACCEL, o["grav"]),
+                      (B.F_HYDROACCEL, o["hyd"])):
+        assert np.abs(fp.get_field(fid) - want).max() <= 1e-9 * np.abs(want).max(), fid
+    assert relerr(fp.get_field(B.F_ENTROPY), o["entropy"]) < 1e-10
+    assert relerr(fp.get_field(B.F_HSML)[:ng], o["hsml"][:ng]) < 1e-9
+    assert relerr(fp.get_field(B.F_DENSITY), o["density"]) < 1e-9
+    assert np.abs(o["pos"] - pr.ic["pos"]).max() > 1e-6       # the particles did move
+
+
 def test_advance_and_find_timesteps_on_aos_records():
     """The host mirror advance_and_find_timesteps() (timestep.c:29) on P[]/SphP[] records: kick
     results, TimeBin[] and the rebuilt bin lists against the CPU restatement."""
