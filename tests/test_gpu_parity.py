@@ -1157,13 +1157,16 @@ def test_pm_long_range_kick_parity(comoving):
     assert np.abs(want["vel"] - pr.ic["vel"]).max() > 0
 
 
-def test_resident_integration_loop_matches_the_oracle_loop():
+@pytest.mark.parametrize("treepm", [False, True])
+def test_resident_integration_loop_matches_the_oracle_loop(treepm):
     """What row N1 is for: the particle state never leaves HBM between steps.  Three steps of
     run.c's loop -- drift to the sync point, tree build, Newtonian + Ewald walks, density, hmax,
     hydro, timestep + kick -- on the resident fields, against the same loop composed of the oracle's
     restatements.  MaxSizeTimestep binds, so every particle shares one bin and is active in every
     step; after three force computations positions agree to rounding and the kicked quantities to
-    the summation-order tolerance of the forces."""
+    the summation-order tolerance of the forces.  treepm: the c3 flavour -- mesh force on the device
+    at the PM steps (two particle steps long), short-range walk, GravPM in criterion / kick / drift,
+    and the long-range kick with the host-side bookkeeping of timestep.c:273-300."""
     B = bindings()
     pr = Problem(ng=10, gas=True, periodic=1)
     n, ng, box = pr.n, pr.ngas, pr.box
@@ -1177,6 +1180,15 @@ def test_resident_integration_loop_matches_the_oracle_loop():
                TimeBinActive=0xffffffff, logTimeBegin=0.0, logTimeMax=0.0)
     tab = O.ewald_table(box)
     zero_i = np.zeros(n, np.int32)
+    pmgrid = 16
+    asmth = 1.25 * box / pmgrid
+    sr = dict(rcut=4.5 * asmth, asmth=asmth)
+    pm_beg = pm_end = 0                                      # All.PM_Ti_begstep / PM_Ti_endstep
+    dt_disp = 2.0e-3                                         # -> PM step = two particle steps
+    TIMEBASE = 1 << 29
+    o_gpm = np.zeros((n, 3))
+    if treepm:
+        par["pmgrid"], par["dt_displacement"] = 1, dt_disp
     # ---- device state ----
     fp = pr.device()
     for fid in (B.F_TIMEBIN, B.F_TI_BEGSTEP, B.F_TI_CURRENT):
@@ -1196,14 +1208,20 @@ def test_resident_integration_loop_matches_the_oracle_loop():
         d = O.drift(ti, tb, o["pos"], o["vel"], typ, o["ti_current"], o["timebin"],
                     o["ti_begstep"], o["grav"], o["velpred"], o["hyd"], o["density"],
                     o["hsml"][:ng], o["divvel"], o["entropy"], o["dtentropy"], o["pressure"],
-                    wrap=True, boxsize=box)
+                    wrap=True, boxsize=box, gravpm=o_gpm if treepm else None)
         assert d["rc"] == 0
         o["pos"], o["ti_current"], o["velpred"] = d["pos"], d["ti_current"], d["velpred"]
         o["hsml"][:ng] = d["hsml"]
         extent = O.domain_extent(o["pos"])
         T = O.Tree(o["pos"], o["vel"], mass, typ, pr.force_soft, hsml=o["hsml"], extent=extent)
-        acc, cost = T.gravity(pr.o_grav(theta), _all(n), o["oldacc"])
-        T.gravity_ewald_add(pr.o_grav(theta), tab, _all(n), o["oldacc"], acc, cost)
+        pm_step = treepm and pm_end == ti
+        if pm_step:                                          # long_range_force(), accel.c:49-54
+            o_gpm = O.pm_periodic(o["pos"], mass, box, pr.G, pmgrid)
+        if treepm:
+            acc, cost = T.gravity(pr.o_grav(theta, **sr), _all(n), o["oldacc"], kind="shortrange")
+        else:
+            acc, cost = T.gravity(pr.o_grav(theta), _all(n), o["oldacc"])
+            T.gravity_ewald_add(pr.o_grav(theta), tab, _all(n), o["oldacc"], acc, cost)
         o["oldacc"] = np.linalg.norm(acc, axis=1)
         o["grav"] = pr.G * acc
         od = T.density(pr.o_dens(), gas, o["velpred"], o["entropy"], o["dtentropy"], o["timebin"],
@@ -1216,22 +1234,46 @@ def test_resident_integration_loop_matches_the_oracle_loop():
         o["pressure"] = od["pressure"][:ng]
         o["hyd"], o["dtentropy"] = oh["hydroaccel"][:ng], oh["dtentropy"][:ng]
         par["Ti_Current"] = ti
+        if treepm:                                           # timestep.c:66-72
+            par["dt_gravkickB"] = (ti - (pm_beg + pm_end) // 2) * tb
         k = O.advance_timesteps(_fill(O.KickParams(), par, soft), typ, o["vel"], o["grav"],
                                 o["hyd"], o["velpred"], o["entropy"], o["dtentropy"],
                                 o["density"], o["pressure"], o["hsml"][:ng],
-                                oh["maxsignalvel"][:ng], o["timebin"], o["ti_begstep"])
+                                oh["maxsignalvel"][:ng], o["timebin"], o["ti_begstep"],
+                                gravpm=o_gpm if treepm else None)
         assert k["rc"] == 0 and np.all(k["timebin"] == bin_)
         for key in ("vel", "velpred", "entropy", "dtentropy", "timebin", "ti_begstep"):
             o[key] = k[key]
+        pmk = None
+        if pm_step:                                          # timestep.c:269-300, scalar host code
+            ti_step = TIMEBASE
+            while ti_step > dt_disp / tb:
+                ti_step >>= 1
+            if ti_step > pm_end - pm_beg and (TIMEBASE - pm_end) % ti_step > 0:
+                ti_step = pm_end - pm_beg
+            tstart, tend = (pm_beg + pm_end) // 2, pm_end + ti_step // 2
+            pm_beg, pm_end = pm_end, pm_end + ti_step
+            pmk = ((tend - tstart) * tb, -((pm_beg + pm_end) // 2 - pm_beg) * tb)
+            w = O.pm_kick(ti, tb, pmk[0], pmk[1], typ, o["timebin"], o["ti_begstep"], o["vel"],
+                          o["grav"], o_gpm, o["hyd"], o["velpred"])
+            o["vel"], o["velpred"] = w["vel"], w["velpred"]
         # -- device: the same phases on the resident fields, nothing uploaded in between --
-        fp.drift(ti, tb, box_wrap=True, boxsize=box)
+        fp.drift(ti, tb, box_wrap=True, boxsize=box, pmgrid=treepm)
         fp.tree_build(extent[0], extent[1], extent[2], pr.force_soft)
-        fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD)
+        if pm_step:
+            fp.pm_periodic(pmgrid, box, pr.G)
+        if treepm:
+            fp.gravity(pr.g_grav(theta, sr["rcut"], asmth), B.WALK_SHORTRANGE)
+        else:
+            fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD)
         fp.density(pr.g_dens())
         fp.update_hmax()
         fp.hydro(pr.g_hydro())
         fp.gravity_finish(pr.G)
         fp.advance_timesteps(_fill(B.KickParams(), par, soft))
+        if pmk is not None:
+            fp.pm_kick(ti, tb, pmk[0], pmk[1])
+    assert not treepm or (pm_beg, pm_end) == (2 << bin_, 4 << bin_)   # PM steps at Ti = 0 and 2^21
     assert np.abs(fp.get_field(B.F_POS) - o["pos"]).max() < 1e-13
     assert np.array_equal(fp.get_field(B.F_TIMEBIN), o["timebin"])
     assert np.array_equal(fp.get_field(B.F_TI_BEGSTEP), o["ti_begstep"])
@@ -1243,6 +1285,8 @@ def test_resident_integration_loop_matches_the_oracle_loop():
     assert relerr(fp.get_field(B.F_ENTROPY), o["entropy"]) < 1e-10
     assert relerr(fp.get_field(B.F_HSML)[:ng], o["hsml"][:ng]) < 1e-9
     assert relerr(fp.get_field(B.F_DENSITY), o["density"]) < 1e-9
+    if treepm:
+        assert np.abs(fp.get_field(B.F_GRAVPM) - o_gpm).max() <= 1e-10 * np.abs(o_gpm).max()
     assert np.abs(o["pos"] - pr.ic["pos"]).max() > 1e-6       # the particles did move
 
 
