@@ -17,6 +17,14 @@
  *   ghip_update_hmax                      force_update_hmax()          forcetree.c:1661-1786
  *   ghip_hydro                            hydro_force()                hydra.c:145-813, 822-1995
  *   ghip_peano_hilbert_keys               peano_hilbert_key()          peano.c:300-316
+ *   ghip_gravity_finish / _vacuum_energy  OldAcc, *G, Lambda term      gravtree.c:381-403, 470-483
+ *   ghip_set_adaptive_gravsoft            -DADAPTIVE_GRAVSOFT_FORGAS   forcetree.c:705-726, 2038-2139
+ *   ghip_drift                            drift_particle()             predict.c:129-259
+ *   ghip_advance_timesteps / ghip_pm_kick get_timestep, do_the_kick, long-range kick
+ *                                                                      timestep.c:29-605
+ *   ghip_tree_export                      Nodes[] / Extnodes[] / Nextnode[] / Father[] as
+ *                                         force_treebuild leaves them  allvars.h:1847-1916
+ *   ghip_pm_periodic                      pmforce_periodic()           pm_periodic.c:199-800
  * The host-side mirror with the reference's own names (gravity_tree(), density(), hydro_force(),
  * force_treeevaluate(), ...) is include/gadget_force.h.
  */
