@@ -1157,17 +1157,22 @@ def test_pm_long_range_kick_parity(comoving):
     assert np.abs(want["vel"] - pr.ic["vel"]).max() > 0
 
 
-@pytest.mark.parametrize("treepm", [False, True])
-def test_resident_integration_loop_matches_the_oracle_loop(treepm):
-    """What row N1 is for: the particle state never leaves HBM between steps.  Three steps of
-    run.c's loop -- drift to the sync point, tree build, Newtonian + Ewald walks, density, hmax,
-    hydro, timestep + kick -- on the resident fields, against the same loop composed of the oracle's
-    restatements.  MaxSizeTimestep binds, so every particle shares one bin and is active in every
-    step; after three force computations positions agree to rounding and the kicked quantities to
-    the summation-order tolerance of the forces.  treepm: the c3 flavour -- mesh force on the device
-    at the PM steps (two particle steps long), short-range walk, GravPM in criterion / kick / drift,
-    and the long-range kick with the host-side bookkeeping of timestep.c:273-300."""
+@pytest.mark.parametrize("flavour", ["one bin", "treepm", "individual steps"])
+def test_resident_integration_loop_matches_the_oracle_loop(flavour):
+    """What row N1 is for: the particle state never leaves HBM between steps.  run.c's loop --
+    drift to the next sync point, tree build, gravity walks, density, hmax, hydro for the ACTIVE
+    particles, timestep + kick -- on the resident fields, against the same loop composed of the
+    oracle's restatements, nothing uploaded in between.
+      one bin           MaxSizeTimestep binds: everybody shares bin 20 and is active in each of the
+                        three steps (tree + Ewald walks, configuration c2)
+      treepm            the same as configuration c3: mesh force on the device at the PM steps (two
+                        particle steps long), short-range walk, GravPM in criterion / kick / drift,
+                        long-range kick with the host-side bookkeeping of timestep.c:273-300
+      individual steps  the acceleration criterion spreads the particles over several bins; six
+                        sync points with partial active lists, inactive neighbours entering with
+                        their drifted (predicted) state, bins opening only when synchronised"""
     B = bindings()
+    treepm, multi = flavour == "treepm", flavour == "individual steps"
     pr = Problem(ng=10, gas=True, periodic=1)
     n, ng, box = pr.n, pr.ngas, pr.box
     typ, mass = pr.ic["type"], pr.ic["mass"]
@@ -1199,9 +1204,18 @@ def test_resident_integration_loop_matches_the_oracle_loop(treepm):
              entropy=pr.entropy.copy(), dtentropy=pr.dtentropy.copy(), hsml=pr.hsml0.copy(),
              timebin=zero_i.copy(), ti_begstep=zero_i.copy(), ti_current=zero_i.copy(),
              oldacc=np.zeros(n), grav=np.zeros((n, 3)), hyd=np.zeros((ng, 3)),
-             density=np.ones(ng), divvel=np.zeros(ng), pressure=np.zeros(ng))
-    gas = _all(ng)
-    for step, ti in enumerate((0, 1 << bin_, 2 << bin_)):
+             density=np.ones(ng), divvel=np.zeros(ng), pressure=np.zeros(ng),
+             dhsmlfac=np.ones(ng), curlvel=np.zeros(ng), vsig=np.zeros(ng))
+    ti, visited, nact_seen = 0, [], []
+    for step in range(6 if multi else 3):
+        # the particles whose step ends at this sync point (run.c:300-320)
+        ends = o["ti_begstep"] + np.where(o["timebin"] > 0, 1 << o["timebin"], 0)
+        act = np.where(ends == ti)[0].astype(np.int32)
+        gas = act[act < ng]
+        allact = len(act) == n
+        visited.append(ti)
+        nact_seen.append(len(act))
+        par["TimeBinActive"] = sum(1 << b for b in range(30) if ti % (1 << b) == 0)  # timestep.c:163
         pr.ti_current = ti
         theta = pr.theta if step == 0 else 0.0           # accel.c:61-68: first pass Barnes-Hut
         # -- oracle: drift_particle for everybody (run.c find_next_sync_point_and_drift) --
@@ -1211,37 +1225,45 @@ def test_resident_integration_loop_matches_the_oracle_loop(treepm):
                     wrap=True, boxsize=box, gravpm=o_gpm if treepm else None)
         assert d["rc"] == 0
         o["pos"], o["ti_current"], o["velpred"] = d["pos"], d["ti_current"], d["velpred"]
-        o["hsml"][:ng] = d["hsml"]
+        o["hsml"][:ng], o["density"], o["pressure"] = d["hsml"], d["density"], d["pressure"]
         extent = O.domain_extent(o["pos"])
         T = O.Tree(o["pos"], o["vel"], mass, typ, pr.force_soft, hsml=o["hsml"], extent=extent)
         pm_step = treepm and pm_end == ti
         if pm_step:                                          # long_range_force(), accel.c:49-54
             o_gpm = O.pm_periodic(o["pos"], mass, box, pr.G, pmgrid)
         if treepm:
-            acc, cost = T.gravity(pr.o_grav(theta, **sr), _all(n), o["oldacc"], kind="shortrange")
+            acc, cost = T.gravity(pr.o_grav(theta, **sr), act, o["oldacc"], kind="shortrange")
         else:
-            acc, cost = T.gravity(pr.o_grav(theta), _all(n), o["oldacc"])
-            T.gravity_ewald_add(pr.o_grav(theta), tab, _all(n), o["oldacc"], acc, cost)
-        o["oldacc"] = np.linalg.norm(acc, axis=1)
-        o["grav"] = pr.G * acc
-        od = T.density(pr.o_dens(), gas, o["velpred"], o["entropy"], o["dtentropy"], o["timebin"],
-                       o["ti_begstep"], o["hsml"])
-        T.update_hmax(gas, od["hsml"], od["divvel"])
-        oh = T.hydro(pr.o_hydro(), gas, o["velpred"], od["hsml"], od["density"], od["pressure"],
-                     od["dhsmlfac"], od["divvel"], od["curlvel"], o["timebin"])
-        o["hsml"] = od["hsml"]
-        o["density"], o["divvel"] = od["density"][:ng], od["divvel"][:ng]
-        o["pressure"] = od["pressure"][:ng]
-        o["hyd"], o["dtentropy"] = oh["hydroaccel"][:ng], oh["dtentropy"][:ng]
+            acc, cost = T.gravity(pr.o_grav(theta), act, o["oldacc"])
+            T.gravity_ewald_add(pr.o_grav(theta), tab, act, o["oldacc"], acc, cost)
+        o["oldacc"][act] = np.linalg.norm(acc, axis=1)
+        o["grav"][act] = pr.G * acc
+        if len(gas):
+            od = T.density(pr.o_dens(), gas, o["velpred"], o["entropy"], o["dtentropy"],
+                           o["timebin"], o["ti_begstep"], o["hsml"])
+            for key in ("density", "divvel", "pressure", "dhsmlfac", "curlvel"):
+                o[key][gas] = od[key][gas]
+            o["hsml"][gas] = od["hsml"][gas]
+            T.update_hmax(gas, o["hsml"], np.concatenate([o["divvel"], np.zeros(n - ng)]))
+            full = lambda a: np.concatenate([a, np.zeros(n - ng)])      # noqa: E731
+            oh = T.hydro(pr.o_hydro(), gas, o["velpred"], o["hsml"], full(o["density"]),
+                         full(o["pressure"]), full(o["dhsmlfac"]), full(o["divvel"]),
+                         full(o["curlvel"]), o["timebin"])
+            o["hyd"][gas], o["dtentropy"][gas] = oh["hydroaccel"][gas], oh["dtentropy"][gas]
+            o["vsig"][gas] = oh["maxsignalvel"][gas]
+        if multi and step == 0:
+            # spread the particles over a few bins: median acceleration-criterion step = 0.7e-3
+            amed = np.median(np.linalg.norm(o["grav"], axis=1))
+            par["ErrTolIntAccuracy"] = (0.7e-3) ** 2 * amed / (2 * soft[1])
         par["Ti_Current"] = ti
         if treepm:                                           # timestep.c:66-72
             par["dt_gravkickB"] = (ti - (pm_beg + pm_end) // 2) * tb
         k = O.advance_timesteps(_fill(O.KickParams(), par, soft), typ, o["vel"], o["grav"],
                                 o["hyd"], o["velpred"], o["entropy"], o["dtentropy"],
-                                o["density"], o["pressure"], o["hsml"][:ng],
-                                oh["maxsignalvel"][:ng], o["timebin"], o["ti_begstep"],
+                                o["density"], o["pressure"], o["hsml"][:ng], o["vsig"],
+                                o["timebin"], o["ti_begstep"], active=None if allact else act,
                                 gravpm=o_gpm if treepm else None)
-        assert k["rc"] == 0 and np.all(k["timebin"] == bin_)
+        assert k["rc"] == 0
         for key in ("vel", "velpred", "entropy", "dtentropy", "timebin", "ti_begstep"):
             o[key] = k[key]
         pmk = None
@@ -1260,6 +1282,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(treepm):
         # -- device: the same phases on the resident fields, nothing uploaded in between --
         fp.drift(ti, tb, box_wrap=True, boxsize=box, pmgrid=treepm)
         fp.tree_build(extent[0], extent[1], extent[2], pr.force_soft)
+        fp.set_active(None if allact else act)
         if pm_step:
             fp.pm_periodic(pmgrid, box, pr.G)
         if treepm:
@@ -1273,12 +1296,18 @@ def test_resident_integration_loop_matches_the_oracle_loop(treepm):
         fp.advance_timesteps(_fill(B.KickParams(), par, soft))
         if pmk is not None:
             fp.pm_kick(ti, tb, pmk[0], pmk[1])
+        assert np.array_equal(fp.get_field(B.F_TIMEBIN), o["timebin"]), (step, ti)
+        assert np.array_equal(fp.get_field(B.F_GRAVCOST)[act], cost), (step, ti)
+        ti = int((o["ti_begstep"] + (1 << o["timebin"])).min())      # next sync point
+    if multi:
+        assert len(np.unique(o["timebin"])) >= 3 and min(nact_seen[1:]) < n // 2
+        assert visited[1] < (1 << bin_)                  # sub-steps of the largest bin were taken
+    else:
+        assert visited == [0, 1 << bin_, 2 << bin_] and np.all(o["timebin"] == bin_)
     assert not treepm or (pm_beg, pm_end) == (2 << bin_, 4 << bin_)   # PM steps at Ti = 0 and 2^21
     assert np.abs(fp.get_field(B.F_POS) - o["pos"]).max() < 1e-13
-    assert np.array_equal(fp.get_field(B.F_TIMEBIN), o["timebin"])
     assert np.array_equal(fp.get_field(B.F_TI_BEGSTEP), o["ti_begstep"])
     assert np.array_equal(fp.get_field(B.F_TI_CURRENT), o["ti_current"])
-    assert np.array_equal(fp.get_field(B.F_GRAVCOST), cost)
     for fid, want in ((B.F_VEL, o["vel"]), (B.F_VELPRED, o["velpred"]), (B.F_GRAVACCEL, o["grav"]),
                       (B.F_HYDROACCEL, o["hyd"])):
         assert np.abs(fp.get_field(fid) - want).max() <= 1e-9 * np.abs(want).max(), fid
