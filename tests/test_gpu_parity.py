@@ -734,6 +734,55 @@ def test_compute_accelerations_sequence_on_aos_records():
     host.close()
 
 
+def test_records_with_hsml_in_particle_data_like_the_shipped_bundle():
+    """BLACK_HOLES || DUST (the shipped Makefile bundle, config c5) move Hsml and NumNgb from SphP
+    into P -- the PPP macro, allvars.h:266-270 -- and pad the records with hundreds of bytes the
+    path never touches.  Through the offsets table that is just another layout: density results
+    land in P[].Hsml / P[].n.NumNgb of the gas records, everything else in the 536-byte records is
+    returned untouched, and the numbers are those of the SoA path."""
+    B = bindings()
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    pr = Problem(ng=8, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    pdt = np.dtype({"names": ["Pos", "Vel", "Mass", "ID", "GravAccel", "OldAcc", "GravCost",
+                              "Ti_begstep", "Ti_current", "Type", "TimeBin", "Hsml", "NumNgb",
+                              "bh_dust_unions"],
+                    "formats": [("f8", 3), ("f8", 3), "f8", "u4", ("f8", 3), "f8", "f4", "i4", "i4",
+                                "i2", "i2", "f8", "f8", ("u1", 408)],
+                    "offsets": [0, 24, 48, 56, 64, 88, 96, 100, 104, 108, 110, 112, 120, 128],
+                    "itemsize": 536})                       # SURVEY 8a a1: 536 B shipped bundle
+    P = np.zeros(n, pdt)
+    P["Pos"], P["Vel"], P["Mass"], P["Type"] = pr.ic["pos"], pr.ic["vel"], pr.ic["mass"], pr.ic["type"]
+    P["TimeBin"], P["Ti_begstep"], P["Hsml"] = pr.timebin, pr.ti_begstep, pr.hsml0
+    P["NumNgb"] = -5.0                                      # sentinel: only gas records may change
+    rng = np.random.default_rng(9)
+    P["bh_dust_unions"] = rng.integers(0, 255, (n, 408), dtype=np.uint8)
+    S = np.zeros(ng, H.SPH_DTYPE)
+    S["VelPred"], S["Entropy"], S["DtEntropy"] = pr.velpred, pr.entropy, pr.dtentropy
+    lay = B.Layout()
+    H.lib().gadget_force_layout(C.byref(lay))               # the SphP offsets of the mirror ...
+    lay.s_hsml = lay.s_numngb = -1                          # ... but Hsml / NumNgb live in P
+    lay.p_stride = 536
+    lay.p_hsml, lay.p_numngb = pdt.fields["Hsml"][1], pdt.fields["NumNgb"][1]
+    keep = P.copy()
+    fp = B.ForcePath(0)
+    fp.upload_aos(P, S, lay)
+    assert np.array_equal(fp.get_field(B.F_HSML), pr.hsml0)
+    pr.device_tree(fp)
+    fp.density(pr.g_dens())
+    fp.download_aos(P, S, lay, gravity=False, density=True, hydro=False)
+    ref = pr.device()
+    pr.device_tree(ref)
+    ref.density(pr.g_dens())
+    assert np.array_equal(P["Hsml"][:ng], ref.get_field(B.F_HSML)[:ng])
+    assert np.array_equal(P["NumNgb"][:ng], ref.get_field(B.F_NUMNGB))
+    assert np.array_equal(S["Density"], ref.get_field(B.F_DENSITY))
+    assert np.all(np.abs(P["NumNgb"][:ng] - pr.des_ngb) <= pr.max_dev + 1e-9)
+    assert np.all(P["NumNgb"][ng:] == -5.0) and np.array_equal(P["Hsml"][ng:], pr.hsml0[ng:])
+    for name in ("Pos", "Vel", "Mass", "ID", "Type", "bh_dust_unions", "GravAccel"):
+        assert np.array_equal(P[name], keep[name]), name
+
+
 def test_pmgrid_records_carry_gravpm_through_the_offsets_table():
     """A PMGRID build's struct particle_data is 136 bytes with GravPM[3] behind GravAccel
     (allvars.h:1180-1183).  The library only sees byte offsets: GravPM is uploaded
