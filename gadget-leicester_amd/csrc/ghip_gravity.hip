@@ -43,20 +43,17 @@ __global__ void k_grav_vacuum(int nt, const int *__restrict__ tgt, const int *__
 __global__ void __launch_bounds__(256)
 k_grav_direct(int n, const double *__restrict__ sx, const double *__restrict__ sy,
               const double *__restrict__ sz, const double4 *__restrict__ xm,
-              const int4 *__restrict__ lk, int nelem, const double *__restrict__ ssoft, int nt,
-              const int *__restrict__ tgt, GravK p, double *__restrict__ ax,
-              double *__restrict__ ay, double *__restrict__ az)
+              const double *__restrict__ ssoft, int nt, const int *__restrict__ tgt, GravK p,
+              double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az)
 {
-  // sources are read straight from the sorted arrays; mass comes from the element list is
-  // avoided by passing per-particle mass in xm? -- kept simple: masses are gathered below
+  // sources in tree order: positions from the sorted planes, mass from xm[j].w (a per-particle
+  // (x,y,z,m) array the caller gathers), softening from ssoft; 256 of them per LDS tile
   __shared__ double lx[256], ly[256], lz[256], lm[256], ls[256];
   int ti = blockIdx.x * 256 + threadIdx.x;
   bool valid = ti < nt;
   int s = valid ? tgt[ti] : 0;
   double px = sx[s], py = sy[s], pz = sz[s], hi = ssoft[s];
   double a0 = 0, a1 = 0, a2 = 0;
-  (void) lk;
-  (void) nelem;
   for(int base = 0; base < n; base += 256)
     {
       int j = base + threadIdx.x;
@@ -65,7 +62,7 @@ k_grav_direct(int n, const double *__restrict__ sx, const double *__restrict__ s
           lx[threadIdx.x] = sx[j];
           ly[threadIdx.x] = sy[j];
           lz[threadIdx.x] = sz[j];
-          lm[threadIdx.x] = xm[j].w;  // caller passes a per-particle (x,y,z,m) array here
+          lm[threadIdx.x] = xm[j].w;
           ls[threadIdx.x] = ssoft[j];
         }
       __syncthreads();
@@ -786,8 +783,8 @@ extern "C" int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p)
                                             P<double>(ctx->f[GHIP_F_MASS]),
                                             P<double4>(ctx->stage));
   k_grav_direct<<<cdiv(nt, 256), 256, 0, st>>>(n, P<double>(ctx->sx), P<double>(ctx->sy),
-                                               P<double>(ctx->sz), P<double4>(ctx->stage), nullptr,
-                                               0, P<double>(ctx->ssoft), nt, tgt, k,
+                                               P<double>(ctx->sz), P<double4>(ctx->stage),
+                                               P<double>(ctx->ssoft), nt, tgt, k,
                                                P<double>(ctx->tax), P<double>(ctx->tay),
                                                P<double>(ctx->taz));
   HIPCHK(hipMemsetAsync(ctx->tcost.p, 0, (size_t) nt * 4, st));
