@@ -1206,7 +1206,7 @@ def test_pm_long_range_kick_parity(comoving):
     assert np.abs(want["vel"] - pr.ic["vel"]).max() > 0
 
 
-@pytest.mark.parametrize("flavour", ["one bin", "treepm", "individual steps"])
+@pytest.mark.parametrize("flavour", ["one bin", "treepm", "individual steps", "comoving"])
 def test_resident_integration_loop_matches_the_oracle_loop(flavour):
     """What row N1 is for: the particle state never leaves HBM between steps.  run.c's loop --
     drift to the next sync point, tree build, gravity walks, density, hmax, hydro for the ACTIVE
@@ -1219,19 +1219,32 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
                         long-range kick with the host-side bookkeeping of timestep.c:273-300
       individual steps  the acceleration criterion spreads the particles over several bins; six
                         sync points with partial active lists, inactive neighbours entering with
-                        their drifted (predicted) state, bins opening only when synchronised"""
+                        their drifted (predicted) state, bins opening only when synchronised
+      comoving          ComovingIntegrationOn: logarithmic timeline, drift / kick factors from the
+                        tables, a-dependent factors in the criterion, the kick and the viscosity"""
     B = bindings()
     treepm, multi = flavour == "treepm", flavour == "individual steps"
+    comoving = flavour == "comoving"
     pr = Problem(ng=10, gas=True, periodic=1)
     n, ng, box = pr.n, pr.ngas, pr.box
     typ, mass = pr.ic["type"], pr.ic["mass"]
     bin_, tb = 20, 1.0e-3 / (1 << 20)
+    tabs, tkw, lnb = None, {}, 0.0
+    if comoving:
+        # a logarithmic timeline from a = 0.02 to 1 and smooth stand-ins for the integrals of
+        # driftfac.c:33-58 (both sides interpolate the same tables; init_drift_table needs GSL)
+        lnb = np.log(0.02)
+        tb = (0.0 - lnb) / (1 << 29)
+        bin_ = 17                                            # 1e-3 / tb = 1.37e5 -> 2^17 ticks
+        t = np.linspace(0.01, 1.0, 1000)
+        tabs = [np.cumsum(t ** 1.5) * 1e-3, np.cumsum(t ** 0.5) * 1e-3, np.cumsum(t ** 0.2) * 1e-3]
+        tkw = dict(tables=tabs, log_time_begin=lnb, log_time_max=0.0)
     pr.timebase = tb
     soft = pr.force_soft / 2.8
-    par = dict(Timebase_interval=tb, ComovingIntegrationOn=0, Time=1.0, hubble_a=1.0,
+    par = dict(Timebase_interval=tb, ComovingIntegrationOn=int(comoving), Time=1.0, hubble_a=1.0,
                ErrTolIntAccuracy=1.0e3, CourantFac=1.0e3, MaxSizeTimestep=1.0e-3,
                MinSizeTimestep=0.0, dt_displacement=1.0, MinEgySpec=0.0,
-               TimeBinActive=0xffffffff, logTimeBegin=0.0, logTimeMax=0.0)
+               TimeBinActive=0xffffffff, logTimeBegin=lnb, logTimeMax=0.0)
     tab = O.ewald_table(box)
     zero_i = np.zeros(n, np.int32)
     pmgrid = 16
@@ -1266,12 +1279,19 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
         nact_seen.append(len(act))
         par["TimeBinActive"] = sum(1 << b for b in range(30) if ti % (1 << b) == 0)  # timestep.c:163
         pr.ti_current = ti
+        hyd_args = ()
+        if comoving:                                         # run.c set_ti / hydra.c:192-208
+            a = float(np.exp(lnb + ti * tb))
+            hub = 0.1 * np.sqrt(0.3 / a ** 3 + 0.7)
+            par["Time"], par["hubble_a"] = a, hub
+            hyd_args = (1, a * a * hub, a ** (3 * (1.4 - 1) / 2) / a,
+                        hub * a ** (3 * (1.4 - 1) / 2))
         theta = pr.theta if step == 0 else 0.0           # accel.c:61-68: first pass Barnes-Hut
         # -- oracle: drift_particle for everybody (run.c find_next_sync_point_and_drift) --
         d = O.drift(ti, tb, o["pos"], o["vel"], typ, o["ti_current"], o["timebin"],
                     o["ti_begstep"], o["grav"], o["velpred"], o["hyd"], o["density"],
                     o["hsml"][:ng], o["divvel"], o["entropy"], o["dtentropy"], o["pressure"],
-                    wrap=True, boxsize=box, gravpm=o_gpm if treepm else None)
+                    wrap=True, boxsize=box, gravpm=o_gpm if treepm else None, **tkw)
         assert d["rc"] == 0
         o["pos"], o["ti_current"], o["velpred"] = d["pos"], d["ti_current"], d["velpred"]
         o["hsml"][:ng], o["density"], o["pressure"] = d["hsml"], d["density"], d["pressure"]
@@ -1295,7 +1315,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
             o["hsml"][gas] = od["hsml"][gas]
             T.update_hmax(gas, o["hsml"], np.concatenate([o["divvel"], np.zeros(n - ng)]))
             full = lambda a: np.concatenate([a, np.zeros(n - ng)])      # noqa: E731
-            oh = T.hydro(pr.o_hydro(), gas, o["velpred"], o["hsml"], full(o["density"]),
+            oh = T.hydro(pr.o_hydro(*hyd_args), gas, o["velpred"], o["hsml"], full(o["density"]),
                          full(o["pressure"]), full(o["dhsmlfac"]), full(o["divvel"]),
                          full(o["curlvel"]), o["timebin"])
             o["hyd"][gas], o["dtentropy"][gas] = oh["hydroaccel"][gas], oh["dtentropy"][gas]
@@ -1311,7 +1331,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
                                 o["hyd"], o["velpred"], o["entropy"], o["dtentropy"],
                                 o["density"], o["pressure"], o["hsml"][:ng], o["vsig"],
                                 o["timebin"], o["ti_begstep"], active=None if allact else act,
-                                gravpm=o_gpm if treepm else None)
+                                gravpm=o_gpm if treepm else None, tables=tabs)
         assert k["rc"] == 0
         for key in ("vel", "velpred", "entropy", "dtentropy", "timebin", "ti_begstep"):
             o[key] = k[key]
@@ -1329,7 +1349,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
                           o["grav"], o_gpm, o["hyd"], o["velpred"])
             o["vel"], o["velpred"] = w["vel"], w["velpred"]
         # -- device: the same phases on the resident fields, nothing uploaded in between --
-        fp.drift(ti, tb, box_wrap=True, boxsize=box, pmgrid=treepm)
+        fp.drift(ti, tb, box_wrap=True, boxsize=box, pmgrid=treepm, **tkw)
         fp.tree_build(extent[0], extent[1], extent[2], pr.force_soft)
         fp.set_active(None if allact else act)
         if pm_step:
@@ -1340,9 +1360,10 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
             fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD)
         fp.density(pr.g_dens())
         fp.update_hmax()
-        fp.hydro(pr.g_hydro())
+        fp.hydro(pr.g_hydro(*hyd_args))
         fp.gravity_finish(pr.G)
-        fp.advance_timesteps(_fill(B.KickParams(), par, soft))
+        fp.advance_timesteps(_fill(B.KickParams(), par, soft),
+                             kick_tables=None if tabs is None else tabs[1:])
         if pmk is not None:
             fp.pm_kick(ti, tb, pmk[0], pmk[1])
         assert np.array_equal(fp.get_field(B.F_TIMEBIN), o["timebin"]), (step, ti)
@@ -1365,7 +1386,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
     assert relerr(fp.get_field(B.F_DENSITY), o["density"]) < 1e-9
     if treepm:
         assert np.abs(fp.get_field(B.F_GRAVPM) - o_gpm).max() <= 1e-10 * np.abs(o_gpm).max()
-    assert np.abs(o["pos"] - pr.ic["pos"]).max() > 1e-6       # the particles did move
+    assert np.abs(o["pos"] - pr.ic["pos"]).max() > 1e-8       # the particles did move
 
 
 def test_advance_and_find_timesteps_on_aos_records():
