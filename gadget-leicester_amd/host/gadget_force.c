@@ -432,6 +432,42 @@ static void fill_hydro_params(ghip_hydro_params *h, int raw)
   h->raw_dtentropy = raw;
 }
 
+/* "next" row N2: the host's own walks (potential.c, black-hole / dust neighbour loops) get the
+ * device-built tree in their arrays, when the host has set them */
+static int export_tree_to_host(void)
+{
+  if(!(Nodes_base && Extnodes_base && Nextnode && Father))
+    return 0;
+  ghip_node_layout nl;
+  memset(&nl, 0xff, sizeof(nl));
+  nl.node_stride = (int) sizeof(struct NODE);
+  nl.n_len = (int) offsetof(struct NODE, len);
+  nl.n_center = (int) offsetof(struct NODE, center);
+  nl.n_s = (int) offsetof(struct NODE, u.d.s);
+  nl.n_mass = (int) offsetof(struct NODE, u.d.mass);
+  nl.n_bitflags = (int) offsetof(struct NODE, u.d.bitflags);
+  nl.n_sibling = (int) offsetof(struct NODE, u.d.sibling);
+  nl.n_nextnode = (int) offsetof(struct NODE, u.d.nextnode);
+  nl.n_father = (int) offsetof(struct NODE, u.d.father);
+  nl.n_ti_current = (int) offsetof(struct NODE, Ti_current);
+  nl.ext_stride = (int) sizeof(struct extNODE);
+  nl.e_dp = (int) offsetof(struct extNODE, dp);
+  nl.e_vs = (int) offsetof(struct extNODE, vs);
+  nl.e_vmax = (int) offsetof(struct extNODE, vmax);
+  nl.e_divvmax = (int) offsetof(struct extNODE, divVmax);
+  nl.e_hmax = (int) offsetof(struct extNODE, hmax);
+  nl.e_ti_lastkicked = (int) offsetof(struct extNODE, Ti_lastkicked);
+  nl.e_flag = (int) offsetof(struct extNODE, Flag);
+  int nn = 0;
+  if(chk(ghip_tree_export(Ctx, &nl, All.MaxPart, All.Ti_Current, Cfg.unequal_softenings, Nodes_base,
+                          Extnodes_base, Nextnode, Father, MaxNodes, &nn),
+         "ghip_tree_export"))
+    return -1;
+  Nodes = Nodes_base - All.MaxPart;       /* forcetree.c:4585-4590 */
+  Extnodes = Extnodes_base - All.MaxPart;
+  return 0;
+}
+
 /* forcetree.c:67-103: (re)build the tree over the current particles */
 int force_treebuild(int npart, void *mp)
 {
@@ -453,37 +489,8 @@ int force_treebuild(int npart, void *mp)
   ghip_get_stats(Ctx, &st);
   (void) npart;
   Numnodestree = st.tree_nodes;
-  if(Nodes_base && Extnodes_base && Nextnode && Father)
-    {
-      /* "next" row N2: the host's own walks (potential.c, ...) get the tree in their arrays */
-      ghip_node_layout nl;
-      memset(&nl, 0xff, sizeof(nl));
-      nl.node_stride = (int) sizeof(struct NODE);
-      nl.n_len = (int) offsetof(struct NODE, len);
-      nl.n_center = (int) offsetof(struct NODE, center);
-      nl.n_s = (int) offsetof(struct NODE, u.d.s);
-      nl.n_mass = (int) offsetof(struct NODE, u.d.mass);
-      nl.n_bitflags = (int) offsetof(struct NODE, u.d.bitflags);
-      nl.n_sibling = (int) offsetof(struct NODE, u.d.sibling);
-      nl.n_nextnode = (int) offsetof(struct NODE, u.d.nextnode);
-      nl.n_father = (int) offsetof(struct NODE, u.d.father);
-      nl.n_ti_current = (int) offsetof(struct NODE, Ti_current);
-      nl.ext_stride = (int) sizeof(struct extNODE);
-      nl.e_dp = (int) offsetof(struct extNODE, dp);
-      nl.e_vs = (int) offsetof(struct extNODE, vs);
-      nl.e_vmax = (int) offsetof(struct extNODE, vmax);
-      nl.e_divvmax = (int) offsetof(struct extNODE, divVmax);
-      nl.e_hmax = (int) offsetof(struct extNODE, hmax);
-      nl.e_ti_lastkicked = (int) offsetof(struct extNODE, Ti_lastkicked);
-      nl.e_flag = (int) offsetof(struct extNODE, Flag);
-      int nn = 0;
-      if(chk(ghip_tree_export(Ctx, &nl, All.MaxPart, All.Ti_Current, Cfg.unequal_softenings,
-                              Nodes_base, Extnodes_base, Nextnode, Father, MaxNodes, &nn),
-             "ghip_tree_export"))
-        return -1;
-      Nodes = Nodes_base - All.MaxPart;       /* forcetree.c:4585-4590 */
-      Extnodes = Extnodes_base - All.MaxPart;
-    }
+  if(export_tree_to_host())
+    return -1;
   CPU_Step_Treebuild += wallclock() - t0;
   return Numnodestree;
 }
@@ -611,7 +618,12 @@ void force_update_hmax(void)
   if(need_ctx("force_update_hmax"))
     return;
   double t0 = wallclock();
-  chk(ghip_update_hmax(Ctx), "ghip_update_hmax");
+  if(chk(ghip_update_hmax(Ctx), "ghip_update_hmax"))
+    return;
+  /* the reference refreshes Extnodes[].hmax / divVmax in place (forcetree.c:1661-1786): a host that
+   * holds the exported tree gets it again with the new smoothing lengths and divergences */
+  if(TreeOnDevice)
+    export_tree_to_host();
   CPU_Step_Hmaxupdate += wallclock() - t0;
 }
 

@@ -867,6 +867,14 @@ def test_force_treebuild_fills_the_hosts_tree_arrays():
                 count += 1
             no = nd["sibling"]
         assert count == int(P["GravCost"][i])
+    # force_update_hmax() refreshes Extnodes[].hmax / divVmax in the host's arrays too
+    # (forcetree.c:1661-1786): after density() the root carries the largest new smoothing length
+    hmax_before = ext["hmax"][0]
+    L.density()
+    L.force_update_hmax()
+    assert host.endrun_codes == []
+    assert ext["hmax"][0] == S["Hsml"].max() and ext["hmax"][0] != hmax_before
+    assert ext["divVmax"][0] == max(0.0, S["DivVel"].max()) > 0      # signed, floor 0 (:531, 679)
     host.close()
 
 
