@@ -1,0 +1,97 @@
+"""Development aid: seeded random sweeps of the parity checks -- particle numbers, distributions
+(plane-wave clustered lattices, Plummer spheres, uniform noise), periodic / open boundaries, equal /
+unequal softenings, full and partial active lists -- device against the oracle, counts exactly.
+python tests/gpu_fuzz.py [nseeds]"""
+import sys
+import time
+
+import numpy as np
+
+from common import O, Problem, bindings, ics, relerr
+
+B = bindings()
+TOL = 1e-11
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 3)
+    periodic = int(rng.integers(0, 2))
+    unequal = bool(rng.integers(0, 2))
+    if kind == 0:
+        ic = ics.make_ics(int(rng.integers(3, 13)), gas=True, seed=int(seed), clustered=True,
+                          rms_disp=float(rng.uniform(0.2, 2.0)))
+    elif kind == 1:
+        ic = ics.make_plummer(int(rng.integers(70, 4000)), seed=int(seed),
+                              a=float(rng.uniform(0.01, 0.1)),
+                              gas_fraction=float(rng.uniform(0.1, 0.6)))
+    else:
+        n = int(rng.integers(2, 1500))
+        ngas = int(rng.integers(0, n))
+        pos = rng.random((n, 3))
+        typ = np.where(np.arange(n) < ngas, 0, rng.integers(1, 6, n)).astype(np.int32)
+        ic = dict(pos=pos, vel=rng.standard_normal((n, 3)), mass=rng.uniform(0.5, 2.0, n) / n,
+                  type=typ, ngas=ngas, boxsize=1.0, spacing=1.0 / max(2.0, n ** (1 / 3)),
+                  id=np.arange(1, n + 1, dtype=np.uint32), u=np.full(ngas, 0.01))
+    pr = Problem(ic=ic, periodic=periodic, unequal=unequal,
+                 des_ngb=float(min(33.0, max(ic["ngas"] - 1, 1))))
+    n, ng = pr.n, pr.ngas
+    fp = pr.device()
+    pr.device_tree(fp)
+    T = pr.oracle_tree()
+    assert fp.stats()["tree_nodes"] == T.numnodes, "node count"
+    # density for every gas particle first: the later partial lists see inactive neighbours with a
+    # valid (computed) state, as in a run
+    allgas = np.arange(ng, dtype=np.int32)
+    sph = ng >= 40
+    if sph:
+        fp.density(pr.g_dens())
+        od = T.density(pr.o_dens(), allgas, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                       pr.ti_begstep, pr.hsml0)
+        assert relerr(fp.get_field(B.F_HSML)[:ng], od["hsml"][:ng]) < TOL, "hsml"
+        assert relerr(fp.get_field(B.F_DENSITY), od["density"][:ng]) < TOL, "density"
+        assert fp.stats()["dens_iterations"] == od["iterations"], "h iterations"
+        fp.update_hmax()
+        T.update_hmax(allgas, od["hsml"], od["divvel"])
+    act = None
+    if rng.random() < 0.5 and n > 4:
+        act = np.sort(rng.choice(n, int(rng.integers(1, n)), replace=False)).astype(np.int32)
+        fp.set_active(act)
+    tg = np.arange(n, dtype=np.int32) if act is None else act
+    old = 0.2 + rng.random(n)
+    fp.set_field(B.F_OLDACC, old)
+    theta = float(rng.choice([0.0, 0.4, 0.8]))
+    fp.gravity(pr.g_grav(theta), B.WALK_NEWTON)
+    oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+    if periodic:
+        fp.ewald_init(pr.box)
+        fp.gravity(pr.g_grav(theta), B.WALK_EWALD)
+        T.gravity_ewald_add(pr.o_grav(theta), O.ewald_table(pr.box), tg, old, oacc, ocost)
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST)[tg], ocost), "gravity counts"
+    scale = np.abs(oacc).max() + 1e-300
+    assert np.abs(fp.get_field(B.F_GRAVACCEL)[tg] - oacc).max() < 1e-10 * scale, "gravity"
+    gas = tg[tg < ng]
+    if sph and len(gas):
+        fp.hydro(pr.g_hydro())
+        oh = T.hydro(pr.o_hydro(), gas, pr.velpred, od["hsml"], od["density"], od["pressure"],
+                     od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
+        ha = fp.get_field(B.F_HYDROACCEL)[gas]
+        want = oh["hydroaccel"][gas]
+        assert fp.stats()["hydro_pairs"] == oh["npairs"], "pairs"
+        assert np.abs(ha - want).max() <= 1e-10 * (np.abs(want).max() + 1e-300), "hydro"
+    return kind, n, ng, periodic, unequal, (None if act is None else len(act))
+
+
+if __name__ == "__main__":
+    nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    t0 = time.time()
+    bad = 0
+    for seed in range(1000, 1000 + nseeds):
+        try:
+            info = one(seed)
+            print("seed %d ok %s" % (seed, info), flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("seed %d FAILED: %s" % (seed, e), flush=True)
+    print("%d seeds, %d failures, %.1f s" % (nseeds, bad, time.time() - t0), flush=True)
+    sys.exit(1 if bad else 0)
