@@ -37,8 +37,15 @@ def one(seed):
                  des_ngb=float(min(33.0, max(ic["ngas"] - 1, 1))))
     n, ng = pr.n, pr.ngas
     fp = pr.device()
+    adaptive = bool(ng > 0 and rng.random() < 0.3)           # ADAPTIVE_GRAVSOFT_FORGAS
+    if adaptive:
+        pr.hsml0[:ng] *= rng.uniform(0.05, 1.0, ng)
+        fp.set_field(B.F_HSML, pr.hsml0)
+        fp.set_adaptive_gravsoft(True)
     pr.device_tree(fp)
     T = pr.oracle_tree()
+    if adaptive:
+        T.adaptive_gravsoft()
     assert fp.stats()["tree_nodes"] == T.numnodes, "node count"
     # density for every gas particle first: the later partial lists see inactive neighbours with a
     # valid (computed) state, as in a run
@@ -61,12 +68,24 @@ def one(seed):
     old = 0.2 + rng.random(n)
     fp.set_field(B.F_OLDACC, old)
     theta = float(rng.choice([0.0, 0.4, 0.8]))
-    fp.gravity(pr.g_grav(theta), B.WALK_NEWTON)
-    oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+    mode = "newton"
     if periodic:
-        fp.ewald_init(pr.box)
-        fp.gravity(pr.g_grav(theta), B.WALK_EWALD)
-        T.gravity_ewald_add(pr.o_grav(theta), O.ewald_table(pr.box), tg, old, oacc, ocost)
+        mode = str(rng.choice(["two calls", "pair", "shortrange"]))
+    if mode == "shortrange":                                 # TreePM short-range walk
+        asmth = 1.25 * pr.box / float(rng.choice([8, 16, 32]))
+        fp.gravity(pr.g_grav(theta, 4.5 * asmth, asmth), B.WALK_SHORTRANGE)
+        oacc, ocost = T.gravity(pr.o_grav(theta, rcut=4.5 * asmth, asmth=asmth), tg, old,
+                                kind="shortrange")
+    else:
+        if mode == "pair":
+            fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD)
+        else:
+            fp.gravity(pr.g_grav(theta), B.WALK_NEWTON)
+        oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+        if mode == "two calls":
+            fp.gravity(pr.g_grav(theta), B.WALK_EWALD)
+        if periodic:
+            T.gravity_ewald_add(pr.o_grav(theta), O.ewald_table(pr.box), tg, old, oacc, ocost)
     assert np.array_equal(fp.get_field(B.F_GRAVCOST)[tg], ocost), "gravity counts"
     scale = np.abs(oacc).max() + 1e-300
     assert np.abs(fp.get_field(B.F_GRAVACCEL)[tg] - oacc).max() < 1e-10 * scale, "gravity"
@@ -79,7 +98,7 @@ def one(seed):
         want = oh["hydroaccel"][gas]
         assert fp.stats()["hydro_pairs"] == oh["npairs"], "pairs"
         assert np.abs(ha - want).max() <= 1e-10 * (np.abs(want).max() + 1e-300), "hydro"
-    return kind, n, ng, periodic, unequal, (None if act is None else len(act))
+    return kind, n, ng, mode, unequal, adaptive, (None if act is None else len(act))
 
 
 if __name__ == "__main__":
