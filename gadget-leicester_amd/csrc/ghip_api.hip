@@ -115,6 +115,12 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         delete ctx;
         return GHIP_EHIP;
       }
+  for(int i = 0; i < 2; i++)
+    if(hipEventCreateWithFlags(&ctx->evt[i], hipEventDisableTiming) != hipSuccess)
+      {
+        delete ctx;
+        return GHIP_EHIP;
+      }
   ctx->evx_ready = true;
   // device counters start at zero (hipMalloc does not clear)
   if(ghip_ensure(ctx, ctx->counters, 64 * 8) != GHIP_OK ||
@@ -177,8 +183,12 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
   if(ctx->evx_ready)
-    for(int i = 0; i < 4; i++)
-      (void) hipEventDestroy(ctx->evx[i]);
+    {
+      for(int i = 0; i < 4; i++)
+        (void) hipEventDestroy(ctx->evx[i]);
+      for(int i = 0; i < 2; i++)
+        (void) hipEventDestroy(ctx->evt[i]);
+    }
   if(ctx->stream2)
     (void) hipStreamDestroy(ctx->stream2);
   if(ctx->stream3)

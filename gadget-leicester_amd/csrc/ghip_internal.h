@@ -98,6 +98,8 @@ struct ghip_ctx
   hipEvent_t evx[4];               // pair ordering: inputs ready / Newton combined / Ewald combined /
                                    // Ewald walk kernel done (ghip_hydro waits for it)
   bool evx_ready = false;
+  hipEvent_t evt[2];               // tree build: fork after the tree-order gather / join (curve_order
+                                   // runs on stream2 next to the element emission on the main stream)
   // adaptive wavefront plan of the gravity walks (ghip_walk.h): per walk kind the elements
   // visited per bucket in the previous call (double-buffered) and the scratch plan arrays
   DevBuf plan_steps[3][2], plan_nsub, plan_woff, plan_wave;

@@ -660,12 +660,13 @@ __global__ void k_peano_hi(int n, int levels, const double *__restrict__ x,
   idx[i] = i;
 }
 
-static int exclusive_sum(ghip_ctx *ctx, const int *in, int *out, int n)
+static int exclusive_sum(ghip_ctx *ctx, const int *in, int *out, int n, hipStream_t on = nullptr)
 {
+  hipStream_t st = on ? on : ctx->stream;
   size_t tb = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, n, ctx->stream));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, n, st));
   GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, in, out, n, ctx->stream));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, in, out, n, st));
   return GHIP_OK;
 }
 
@@ -760,7 +761,8 @@ static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout)
 // element list + moments.  Sorted particle data goes to ox,oy,oz,om,oa; iperm is filled too.
 static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const double *x,
                      const double *y, const double *z, const double *m, const double *aux,
-                     double *ox, double *oy, double *oz, double *om, double *oa, bool grav)
+                     double *ox, double *oy, double *oz, double *om, double *oa, bool grav,
+                     hipEvent_t *fork_after_gather = nullptr)
 {
   hipStream_t st = ctx->stream;
   t.n = n;
@@ -773,6 +775,8 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
   GCHK(ghip_ensure(ctx, t.aux, (size_t) t.nelem * sizeof(double)));
   k_gather5<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
                                           P<int>(t.iperm));
+  if(fork_after_gather)
+    HIPCHK(hipEventRecord(*fork_after_gather, st));
   k_emit_elements<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
     oz, om, oa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
@@ -795,11 +799,10 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
 // Peano-Hilbert order of the tree-order particles: the order in which targets are bucketed.
 // The order only has to make 64 consecutive targets compact, so the sort runs on the leading
 // ceil(log8 n) + 3 digits of the key (at most 10: they fit a 32-bit sort).
-static int curve_order(ghip_ctx *ctx)
+static int curve_order(ghip_ctx *ctx, hipStream_t st)
 {
   TreeDev &g = ctx->gt, &t = ctx->st;
   int n = ctx->n, ng = ctx->ngas;
-  hipStream_t st = ctx->stream;
   GCHK(ghip_ensure(ctx, g.phorder, (size_t) n * 4));
   if(ng > 0)
     GCHK(ghip_ensure(ctx, t.phorder, (size_t) ng * 4));
@@ -835,7 +838,7 @@ static int curve_order(ghip_ctx *ctx)
       GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
       int *flag = P<int>(ctx->dflags), *pos = P<int>(ctx->dtgt_a);
       k_gas_flags_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm), flag);
-      GCHK(exclusive_sum(ctx, flag, pos, n));
+      GCHK(exclusive_sum(ctx, flag, pos, n, st));
       k_gas_compact_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm),
                                                      P<int>(ctx->dtgt_b), pos, P<int>(t.phorder));
       HIPCHK(hipGetLastError());
@@ -927,10 +930,17 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 5 * sizeof(double)));
   GCHK(emit_tree(ctx, ctx->gt, n, hinfo, x, y, z, m, tmp_soft, P<double>(ctx->sx),
                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->stage),
-                 P<double>(ctx->ssoft), true));
+                 P<double>(ctx->ssoft), true, &ctx->evt[0]));
   ctx->gt.built = true;
+  // The curve order of the targets needs the tree-order positions only (the gather at the head of
+  // emit_tree): it runs on a second stream next to the element emission, the moment passes and the
+  // walk records.  Both chains are strings of short launches, so side by side they take the longer
+  // of the two instead of the sum.
+  HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evt[0], 0));
+  GCHK(curve_order(ctx, ctx->stream2));
+  HIPCHK(hipEventRecord(ctx->evt[1], ctx->stream2));
   GCHK(ghip_build_segments(ctx, ctx->gt, true));
-  GCHK(curve_order(ctx));
+  HIPCHK(hipStreamWaitEvent(st, ctx->evt[1], 0));
 
   // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml.  Its order, node
   // counts and curve order are known; the rest of its build is deferred to the first call that
