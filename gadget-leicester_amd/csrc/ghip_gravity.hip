@@ -377,9 +377,10 @@ static int ensure_partials(ghip_ctx *ctx, int nwaves, int slot, PartialBufs &pb)
 
 // wavefront plan of one walk call (see k_plan_nsub): kind 0 Newton/short-range, 1 Ewald,
 // 2 external targets (never has history)
-static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, int slot = 0)
+static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, int slot = 0,
+                      hipStream_t on = nullptr)
 {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = on ? on : ctx->stream;
   DevBuf &b_nsub = slot ? ctx->plan_nsub2 : ctx->plan_nsub, &b_woff = slot ? ctx->plan_woff2 : ctx->plan_woff,
          &b_wave = slot ? ctx->plan_wave2 : ctx->plan_wave, &b_tmp = slot ? ctx->cubtmp2 : ctx->cubtmp;
   int sbase = (49152 + nb - 1) / nb;
@@ -518,17 +519,21 @@ struct WalkJob
   unsigned long long *counter;
 };
 
+// plan_on: the stream the wavefront plan and the counter resets are enqueued on (default: the main
+// stream).  The plan reads only what the previous walk of the same kind left behind, so in a pair
+// the Ewald walk's plan is built on the Ewald stream, next to the Newtonian one on the main stream.
 static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt, int slot,
-                       WalkJob &J)
+                       WalkJob &J, hipStream_t plan_on = nullptr)
 {
+  hipStream_t ps = plan_on ? plan_on : ctx->stream;
   J.walk = walk;
   GCHK(prepare_tables(ctx, p, walk, J.k));
   walk_layout(ctx->gt, nt, J.sg, &J.nbuckets, walk == GHIP_WALK_EWALD);
-  GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, J.nbuckets, J.sg.ns, J.plan, slot));
+  GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, J.nbuckets, J.sg.ns, J.plan, slot, ps));
   GCHK(ensure_partials(ctx, J.plan.nwaves, slot, J.pb));
   J.counter = P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
-  HIPCHK(hipMemsetAsync(J.counter, 0, 8, ctx->stream));
-  HIPCHK(hipMemsetAsync(J.counter + 8, 0, 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(J.counter, 0, 8, ps));
+  HIPCHK(hipMemsetAsync(J.counter + 8, 0, 8, ps));
   return GHIP_OK;
 }
 
@@ -582,7 +587,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   WalkJob A, E;
   GCHK(prepare_job(ctx, p, pair ? GHIP_WALK_NEWTON : walk, nt, 0, A));
   if(pair)
-    GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E));
+    GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E, ctx->stream2));
 
   // OldAcc in tree order (forcetree.c:1850: aold = ErrTolForceAcc * P[target].OldAcc)
   GCHK(ghip_gather_f64(ctx, n, P<int>(ctx->gt.perm), P<double>(ctx->f[GHIP_F_OLDACC]),
