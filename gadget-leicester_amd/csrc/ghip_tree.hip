@@ -936,10 +936,12 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   // emit_tree): it runs on a second stream next to the element emission, the moment passes and the
   // walk records.  Both chains are strings of short launches, so side by side they take the longer
   // of the two instead of the sum.
+  // (the main stream's remaining launches are enqueued first: the host needs longer to enqueue the
+  // curve order's ~25 launches than the device needs to run the main chain)
+  GCHK(ghip_build_segments(ctx, ctx->gt, true));
   HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evt[0], 0));
   GCHK(curve_order(ctx, ctx->stream2));
   HIPCHK(hipEventRecord(ctx->evt[1], ctx->stream2));
-  GCHK(ghip_build_segments(ctx, ctx->gt, true));
   HIPCHK(hipStreamWaitEvent(st, ctx->evt[1], 0));
 
   // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml.  Its order, node
