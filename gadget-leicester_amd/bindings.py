@@ -27,7 +27,8 @@ WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD, WALK_NEWTON_EWALD = 0, 1, 2, 3
 EN = 64
 
 GHIP_ERRORS = {-90001: "GHIP_EHIP", -90002: "GHIP_EINVAL", -90003: "GHIP_ENOMEM",
-               -90004: "GHIP_ENOCONV", -90005: "GHIP_ENODEVICE"}
+               -90004: "GHIP_ENOCONV", -90005: "GHIP_ENODEVICE", -90006: "GHIP_ETIMESTEP",
+               -90008: "GHIP_EDEVICE", -90009: "GHIP_ECOMM"}
 
 
 class Layout(C.Structure):
@@ -146,7 +147,8 @@ EXPORTS = [
     "ghip_create", "ghip_destroy", "ghip_last_error", "ghip_version", "ghip_set_counts",
     "ghip_set_field", "ghip_get_field", "ghip_upload_aos", "ghip_download_aos", "ghip_set_active",
     "ghip_set_shard", "ghip_tree_build", "ghip_ewald_init", "ghip_ewald_get_table", "ghip_gravity",
-    "ghip_gravity_ext", "ghip_gravity_finish", "ghip_gravity_direct", "ghip_density",
+    "ghip_gravity_ext", "ghip_gravity_finish", "ghip_gravity_finish_ex", "ghip_gravity_direct",
+    "ghip_density",
     "ghip_update_hmax", "ghip_hydro", "ghip_density_evaluate", "ghip_ngb_treefind",
     "ghip_peano_hilbert_keys", "ghip_morton_keys", "ghip_get_stats", "ghip_tree_dump",
     "ghip_stream", "ghip_sync", "ghip_shard_pack", "ghip_shard_unpack", "ghip_shard_count",
@@ -187,6 +189,7 @@ def lib():
         L.ghip_pm_kick.argtypes = [vp, C.POINTER(PmKickParams)]
         L.ghip_gravity_finish.argtypes = [vp, C.c_double]
         L.ghip_gravity_finish_all.argtypes = [vp, C.c_double]
+        L.ghip_gravity_finish_ex.argtypes = [vp, C.c_double, C.c_int, C.c_double, C.c_int]
         L.ghip_gravity_direct.argtypes = [vp, C.POINTER(GravParams)]
         L.ghip_density.argtypes = [vp, C.POINTER(DensParams)]
         L.ghip_update_hmax.argtypes = [vp]
@@ -335,6 +338,10 @@ class ForcePath:
 
     def gravity_finish(self, G):
         self._chk(self.L.ghip_gravity_finish(self.h, float(G)))
+
+    def gravity_finish_ex(self, G, pmgrid=False, comoving_fac=0.0, all_shards=False):
+        self._chk(self.L.ghip_gravity_finish_ex(self.h, float(G), int(bool(pmgrid)),
+                                                float(comoving_fac), int(bool(all_shards))))
 
     def gravity_finish_all(self, G):
         self._chk(self.L.ghip_gravity_finish_all(self.h, float(G)))

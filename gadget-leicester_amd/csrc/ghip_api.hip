@@ -57,6 +57,30 @@ int ghip_join(ghip_ctx *ctx)
   return ctx ? ghip_finish_gas_tree(ctx) : GHIP_OK;
 }
 
+// call after a stream synchronisation: has a kernel reported a broken invariant?
+int ghip_check_device_errors(ghip_ctx *ctx)
+{
+  if(!ctx || !ctx->pinned)
+    return GHIP_OK;
+  static const char *what[GHIP_ERRW_COUNT] = {
+    "the wavefront plan of a gravity walk exceeded its grid (ghip_walk.h, k_plan_fill)",
+    "a target had to open a pruned node of an imported (other shard's) tree: the locally "
+    "essential tree was incomplete",
+    "tree emission outside the element list or a malformed imported element",
+    "ghost import", "", "", "", ""};
+  for(int w = 0; w < GHIP_ERRW_COUNT; w++)
+    {
+      volatile int *e = ghip_errword(ctx, w);
+      if(*e != 0)
+        {
+          int v = *e;
+          *e = 0;
+          return ghip_fail(ctx, GHIP_EDEVICE, "device invariant %d broken (%d): %s", w, v, what[w]);
+        }
+    }
+  return GHIP_OK;
+}
+
 static void free_buf(DevBuf &b)
 {
   if(b.p)
@@ -129,6 +153,15 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       delete ctx;
       return GHIP_ENOMEM;
     }
+  // pinned, device-visible host words: tree-build read-back [0..7], device error words [32..39]
+  if(hipHostMalloc(&ctx->pinned, 1024, hipHostMallocDefault) != hipSuccess)
+    {
+      ctx->pinned = nullptr;
+      delete ctx;
+      return GHIP_ENOMEM;
+    }
+  ctx->pinned_cap = 1024;
+  memset(ctx->pinned, 0, 1024);
   // make every event "recorded" so that elapsed-time queries never fault
   for(int i = 0; i < 16; i++)
     (void) hipEventRecord(ctx->ev[i], ctx->stream);
@@ -217,7 +250,7 @@ extern "C" int ghip_sync(ghip_ctx *ctx)
   if(!ctx)
     return GHIP_EINVAL;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return GHIP_OK;
+  return ghip_check_device_errors(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,7 +385,7 @@ extern "C" int ghip_get_field(ghip_ctx *ctx, int field, void *host)
       HIPCHK(hipMemcpyAsync(host, ctx->stage.p, bytes, hipMemcpyDeviceToHost, st));
     }
   HIPCHK(hipStreamSynchronize(st));
-  return GHIP_OK;
+  return ghip_check_device_errors(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,7 +583,7 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
   if(touchS)
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  return GHIP_OK;
+  return ghip_check_device_errors(ctx);
 }
 
 __global__ void k_pack_i16(size_t n, char *__restrict__ rec, int stride, int off,
@@ -607,7 +640,7 @@ extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const g
   if(ng > 0)
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  return GHIP_OK;
+  return ghip_check_device_errors(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -720,7 +753,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   S.ms_kick = el(12, 13);
   S.ms_pm = el(14, 15);
   *out = S;
-  return GHIP_OK;
+  return ghip_check_device_errors(ctx);
 }
 
 extern "C" int ghip_tree_dump(ghip_ctx *ctx, int which, int *nelem, double *xm4, double *cl4,

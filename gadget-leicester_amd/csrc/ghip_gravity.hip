@@ -10,9 +10,13 @@
 
 #include "ghip_walk.h"
 
-// gravtree.c:381-403: OldAcc = |GravAccel| (G-less), then GravAccel *= G
+// the post-pass of gravity_tree (gravtree.c:362-403), in the reference's order:
+//   comoving && !PERIODIC && !PMGRID: GravAccel += 0.5 Hubble^2 Omega0 / G * Pos   (:362-373)
+//   OldAcc = |GravAccel|, under PMGRID |GravAccel + GravPM / G|                    (:375-391)
+//   GravAccel *= G                                                                  (:398-403)
 __global__ void k_grav_finish(int nt, const int *__restrict__ tgt, const int *__restrict__ perm,
-                              int n, double G, double *__restrict__ oacc,
+                              int n, double G, double comoving_fac, const double *__restrict__ pos,
+                              const double *__restrict__ gravpm, double *__restrict__ oacc,
                               double *__restrict__ oldacc)
 {
   int ti = blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +24,20 @@ __global__ void k_grav_finish(int nt, const int *__restrict__ tgt, const int *__
     return;
   int i = perm[tgt[ti]];
   double a0 = oacc[i], a1 = oacc[(size_t) n + i], a2 = oacc[2 * (size_t) n + i];
-  oldacc[i] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  if(comoving_fac != 0)
+    {
+      a0 += comoving_fac * pos[i];
+      a1 += comoving_fac * pos[(size_t) n + i];
+      a2 += comoving_fac * pos[2 * (size_t) n + i];
+    }
+  double b0 = a0, b1 = a1, b2 = a2;
+  if(gravpm)
+    {
+      b0 = a0 + gravpm[i] / G;
+      b1 = a1 + gravpm[(size_t) n + i] / G;
+      b2 = a2 + gravpm[2 * (size_t) n + i] / G;
+    }
+  oldacc[i] = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
   oacc[i] = a0 * G;
   oacc[(size_t) n + i] = a1 * G;
   oacc[2 * (size_t) n + i] = a2 * G;
@@ -421,7 +438,8 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, i
                                           P<int>(b_woff), nb, st));
   HIPCHK(hipMemsetAsync(b_wave.p, 0xff, (size_t) maxwaves * 4, st));
   k_plan_fill<<<cdiv(nb, 256), 256, 0, st>>>(nb, P<int>(b_nsub), P<int>(b_woff),
-                                             maxwaves, P<int>(b_wave), out);
+                                             maxwaves, P<int>(b_wave), out,
+                                             ghip_errword(ctx, GHIP_ERRW_PLAN));
   HIPCHK(hipGetLastError());
   if(kind < 2)
     {
@@ -700,7 +718,10 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
   return ghip_gravity_ext_soft(ctx, p, walk, nt, pos, type, nullptr, oldacc, acc, ninteractions);
 }
 
-extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
+// all_shards != 0: every active target regardless of the shard (multi-GPU, replicated mode: after
+// the all-gather of the sharded walks each rank holds all G-less accelerations)
+extern "C" int ghip_gravity_finish_ex(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac,
+                                      int all_shards)
 {
   if(ctx)
     GHIP_JOIN(ctx);
@@ -708,37 +729,30 @@ extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
     return GHIP_EINVAL;
   if(!ctx->gt.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_finish: no tree");
+  if(pmgrid && !(G != 0))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_finish: PMGRID needs G != 0 (GravPM / G)");
   GCHK(ghip_build_target_lists(ctx));
-  int lo, nt;
-  shard_slice(ctx, ctx->nt_grav, &lo, &nt);
+  int lo = 0, nt = ctx->nt_grav;
+  if(!all_shards)
+    shard_slice(ctx, ctx->nt_grav, &lo, &nt);
   if(nt == 0)
     return GHIP_OK;
   k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
-    nt, P<int>(ctx->tg_grav) + lo, P<int>(ctx->gt.perm), ctx->n, G,
+    nt, P<int>(ctx->tg_grav) + lo, P<int>(ctx->gt.perm), ctx->n, G, comoving_fac,
+    P<double>(ctx->f[GHIP_F_POS]), pmgrid ? P<double>(ctx->f[GHIP_F_GRAVPM]) : nullptr,
     P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
 
-// the same post-pass over EVERY active target regardless of the shard (after the all-gather of
-// the sharded walks each rank holds all G-less accelerations)
+extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)
+{
+  return ghip_gravity_finish_ex(ctx, G, 0, 0.0, 0);
+}
+
 extern "C" int ghip_gravity_finish_all(ghip_ctx *ctx, double G)
 {
-  if(ctx)
-    GHIP_JOIN(ctx);
-  if(!ctx)
-    return GHIP_EINVAL;
-  if(!ctx->gt.built)
-    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_finish_all: no tree");
-  GCHK(ghip_build_target_lists(ctx));
-  int nt = ctx->nt_grav;
-  if(nt == 0)
-    return GHIP_OK;
-  k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
-    nt, P<int>(ctx->tg_grav), P<int>(ctx->gt.perm), ctx->n, G,
-    P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
-  HIPCHK(hipGetLastError());
-  return GHIP_OK;
+  return ghip_gravity_finish_ex(ctx, G, 0, 0.0, 1);
 }
 
 extern "C" int ghip_gravity_vacuum_energy(ghip_ctx *ctx, double fac)

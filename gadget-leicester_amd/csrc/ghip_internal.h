@@ -126,6 +126,19 @@ struct ghip_ctx
 };
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
+// Device error words: ints in pinned, device-visible host memory that kernels set when an internal
+// invariant breaks.  Every synchronising entry point (ghip_sync, ghip_get_field, the AoS downloads,
+// ghip_get_stats) calls ghip_check_device_errors after its stream sync and fails with GHIP_EDEVICE.
+#define GHIP_ERRW_PLAN 0     // wavefront plan of a gravity walk exceeded its grid (ghip_walk.h)
+#define GHIP_ERRW_LET 1      // a target wanted to open a pruned node of another shard's tree
+#define GHIP_ERRW_TREE 2     // tree emission wrote outside the element list / malformed import
+#define GHIP_ERRW_GHOST 3    // spare
+#define GHIP_ERRW_COUNT 8
+static inline int *ghip_errword(ghip_ctx *ctx, int which)
+{
+  return reinterpret_cast<int *>(ctx->pinned) + 32 + which;
+}
+int ghip_check_device_errors(ghip_ctx *ctx);
 // The overlapped Newton+Ewald pair returns with its walks still running on their own streams, so
 // that the SPH phases -- which read and write nothing the walks touch -- can be enqueued on the
 // main stream underneath them.  Every other entry point first makes the main stream wait for the

@@ -887,11 +887,6 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       HIPCHK(hipEventRecord(ctx->ev[1], st));
       return GHIP_OK;
     }
-  if(!ctx->pinned)
-    {
-      HIPCHK(hipHostMalloc(&ctx->pinned, 256, hipHostMallocDefault));
-      ctx->pinned_cap = 256;
-    }
   int *hinfo = reinterpret_cast<int *>(ctx->pinned);  // [0..2] gravity tree, [4..6] gas tree
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
 

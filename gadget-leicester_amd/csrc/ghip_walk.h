@@ -695,14 +695,22 @@ __global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__res
   nsub[b] = s < 1 ? 1 : s;
 }
 
+// The grid and the partial-sum buffers are sized for maxwaves = (S+2)*nb + 8 wavefronts, which
+// bounds sum(nsub) only while counters[8+kind] equals the sum of steps_prev[] (both are written by
+// the same previous launch).  Should that invariant ever break, wavefronts beyond maxwaves would
+// not exist while k_combine_grav still summed their slots: the plan is therefore checked here and
+// an overflow is a hard error (GHIP_E_PLAN in the context's device error word, reported by the
+// next synchronising entry point) instead of silently wrong forces.
 __global__ void k_plan_fill(int nb, const int *__restrict__ nsub, const int *__restrict__ woff,
                             int maxwaves, int *__restrict__ wave_bucket,
-                            unsigned int *__restrict__ steps_out)
+                            unsigned int *__restrict__ steps_out, int *__restrict__ errword)
 {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= nb)
     return;
   int o = woff[b], s = nsub[b];
+  if(o + s > maxwaves)
+    *(volatile int *) errword = 1;
   for(int q = 0; q < s; q++)
     if(o + q < maxwaves)
       wave_bucket[o + q] = b;
@@ -773,7 +781,10 @@ __global__ void k_combine_grav(int nt, WalkPlan plan, const int *__restrict__ tg
   if(ti >= nt)
     return;
   const int bucket = ti >> 6, lane = ti & 63;
-  const int w0 = plan.woff[bucket], nsub = plan.nsub[bucket];
+  const int w0 = plan.woff[bucket];
+  int nsub = plan.nsub[bucket];
+  if(w0 + nsub > plan.nwaves)   // plan overflow (reported by k_plan_fill): stay inside the buffers
+    nsub = plan.nwaves > w0 ? plan.nwaves - w0 : 0;
   double a0 = 0, a1 = 0, a2 = 0;
   int c = 0;
   for(int s = 0; s < nsub; s++)

@@ -549,8 +549,12 @@ void gravity_tree(void)
     walk = GHIP_WALK_NEWTON_EWALD; /* both passes in one call: the two walks share the device */
   if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
     return;
-  /* gravtree.c:381-403 */
-  if(chk(ghip_gravity_finish(Ctx, All.G), "ghip_gravity_finish"))
+  /* gravtree.c:362-403: the comoving term of non-periodic builds without a PM mesh, then
+   * OldAcc = |GravAccel (+ GravPM / G)|, then the multiplication by G */
+  double comoving_fac = 0;
+  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn)
+    comoving_fac = 0.5 * All.Hubble * All.Hubble * All.Omega0 / All.G;
+  if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
     return;
   if(All.TypeOfOpeningCriterion == 1)
     All.ErrTolTheta = 0; /* gravtree.c:396-397 */
@@ -568,17 +572,39 @@ void gravity_tree(void)
   CPU_Step_Treewalk += wallclock() - t0;
 }
 
-/* density.c:1035-1053 */
+/* density.c:1030-1052: gas always; sinks under BLACK_HOLES, dust grains under DUST */
 int density_isactive(int n)
 {
   if(P[n].TimeBin < 0)
     return 0;
-  if(P[n].Type == 5)
+  if(Cfg.black_holes && P[n].Type == 5)
     return 1;
-  if(P[n].Type == 2)
+  if(Cfg.dust && P[n].Type == 2)
     return 1;
   if(P[n].Type == 0)
     return 1;
+  return 0;
+}
+
+/* The device density pass evaluates gas targets.  In a BLACK_HOLES / DUST build the reference also
+ * iterates the smoothing length of active Type-5 / Type-2 particles against the gas tree
+ * (density.c:125, 176, 393 loop over density_isactive) and blackhole.c / the dust loops then read
+ * PPP[].Hsml of those particles: rather than leave them stale, refuse loudly. */
+static int refuse_non_gas_density_targets(const char *who)
+{
+  if(!Cfg.black_holes && !Cfg.dust)
+    return 0;
+  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+    if(P[i].Type != 0 && density_isactive(i))
+      {
+        snprintf(ErrBuf, sizeof(ErrBuf),
+                 "%s: active particle %d of type %d is a density target in this build "
+                 "(BLACK_HOLES / DUST); the device density pass handles gas targets only",
+                 who, i, (int) P[i].Type);
+        fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+        endrun(90007);
+        return -1;
+      }
   return 0;
 }
 
@@ -592,6 +618,8 @@ void density(void)
    * call (init.c:791) re-reads P/SphP */
   if(Phase != 1)
     DeviceFresh = 0;
+  if(refuse_non_gas_density_targets("density"))
+    return;
   if(ensure_tree())
     return;
   int nact = collect_active(1);

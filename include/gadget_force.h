@@ -211,6 +211,9 @@ struct gadget_force_config
   int pmgrid;              /* -DPMGRID=n (0: off): gravity_tree uses the short-range walk */
   int unequal_softenings;  /* -DUNEQUALSOFTENINGS */
   int device;              /* GPU ordinal of this rank */
+  int black_holes;         /* -DBLACK_HOLES (without NO_BH_ACCRETION): Type 5 is a density target
+                              (density.c:1035-1041) */
+  int dust;                /* -DDUST: Type 2 is a density target (density.c:1043-1046) */
 };
 
 /* ---- globals with the reference's names (allvars.c) ---- */

@@ -46,6 +46,10 @@ typedef struct ghip_ctx ghip_ctx;
 #define GHIP_ENOMEM (-90003)     /* device or host allocation failed */
 #define GHIP_ENOCONV (-90004)    /* density h-iteration did not converge (reference: endrun(1155)) */
 #define GHIP_ENODEVICE (-90005)  /* no usable gfx950 device */
+#define GHIP_EDEVICE (-90008)    /* an internal invariant broke on the device (plan overflow, a pruned
+                                  * node of an imported tree that a target had to open, ...); results
+                                  * of the step must not be used */
+#define GHIP_ECOMM (-90009)      /* an RCCL call of the multi-GPU exchange failed */
 #define GHIP_ETIMESTEP (-90006)  /* timestep criterion failed (reference: endrun(888|818|112313));
                                   * the code is returned by ghip_timestep_endrun_code */
 
@@ -322,9 +326,21 @@ int ghip_gravity(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
 int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt,
                      const double *pos, const int *type, const double *oldacc, double *acc,
                      int *ninteractions);
-/* OldAcc = |GravAccel| and GravAccel *= G for the active particles (gravtree.c:381-403) */
+/* the post-pass of gravity_tree() over the active particles, in the reference's order
+ * (gravtree.c:362-403):
+ *   comoving_fac != 0 : GravAccel += comoving_fac * Pos, with comoving_fac = 0.5 * Hubble^2 *
+ *                       Omega0 / G -- the term of comoving runs built without PERIODIC and PMGRID
+ *                       (:362-373); pass 0 otherwise
+ *   OldAcc = |GravAccel|; pmgrid != 0: |GravAccel + GRAVPM / G| (:375-391, the relative opening
+ *                       criterion of a TreePM run sees the total acceleration)
+ *   GravAccel *= G      (:398-403)
+ * all_shards != 0: every active target regardless of ghip_set_shard (replicated multi-GPU mode,
+ * after the all-gather). */
+int ghip_gravity_finish_ex(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac,
+                           int all_shards);
+/* = ghip_gravity_finish_ex(ctx, G, 0, 0, 0) / (ctx, G, 0, 0, 1): builds without PMGRID that are
+ * periodic or not comoving */
 int ghip_gravity_finish(ghip_ctx *ctx, double G);
-/* the same for ALL active particles regardless of the shard (multi-GPU: after the all-gather) */
 int ghip_gravity_finish_all(ghip_ctx *ctx, double G);
 /* GravAccel += fac * Pos for all active particles, fac = OmegaLambda * Hubble^2: the vacuum-energy
  * term of runs in physical coordinates (gravtree.c:470-483, !PERIODIC && !PMGRID &&

@@ -301,6 +301,22 @@ class Tree:
         return out
 
 
+def gravity_finish(acc, G, pos=None, gravpm=None, comoving_fac=0.0):
+    """The post-pass of gravity_tree() over the active particles (gravtree.c:362-403), in the
+    reference's order.  acc: G-less tree accelerations [n,3]; pos: P[].Pos (only with comoving_fac);
+    gravpm: P[].GravPM (PMGRID builds, carries G).  Returns (OldAcc, GravAccel)."""
+    a = np.array(acc, dtype=np.float64, copy=True)
+    if comoving_fac != 0.0:
+        # :362-373  comoving, !PERIODIC, !PMGRID: fac = 0.5 * Hubble^2 * Omega0 / G
+        a = a + comoving_fac * np.asarray(pos, dtype=np.float64)
+    b = a
+    if gravpm is not None:
+        # :379-383  PMGRID: ax = GravAccel[0] + GravPM[0] / All.G ...
+        b = a + np.asarray(gravpm, dtype=np.float64) / G
+    oldacc = np.sqrt(b[:, 0] * b[:, 0] + b[:, 1] * b[:, 1] + b[:, 2] * b[:, 2])   # :389
+    return oldacc, a * G                                                         # :398-403
+
+
 def gravity_direct(pos, mass, ptype, soft, targets, unequal=False, periodic=False, boxsize=1.0,
                    ewald_tab=None):
     pos = _f64(pos)

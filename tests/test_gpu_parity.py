@@ -878,6 +878,36 @@ def test_force_treebuild_fills_the_hosts_tree_arrays():
     host.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "pmgrid", "comoving"])
+def test_gravity_finish_matches_the_post_pass_of_gravity_tree(variant):
+    """ghip_gravity_finish_ex against gravtree.c:362-403 as restated (and pinned by hand in
+    tests/test_oracle_pins.py) by O.gravity_finish: the comoving term enters before OldAcc, a
+    PMGRID build takes OldAcc from GravAccel + GravPM / G, the multiplication by G comes last."""
+    B = bindings()
+    pr = Problem(ng=8, gas=True, periodic=0 if variant == "comoving" else 1)
+    fp = pr.device()
+    pr.device_tree(fp)
+    rng = np.random.default_rng(5)
+    acc = rng.standard_normal((pr.n, 3))
+    gpm = 3.0 * rng.standard_normal((pr.n, 3))
+    G, fac = 43.0071, 0.37
+    fp.set_field(B.F_GRAVACCEL, acc)
+    fp.set_field(B.F_GRAVPM, gpm)
+    fp.set_field(B.F_OLDACC, np.zeros(pr.n))
+    act = np.sort(rng.choice(pr.n, pr.n // 2, replace=False)).astype(np.int32)
+    fp.set_active(act)
+    fp.gravity_finish_ex(G, pmgrid=(variant == "pmgrid"),
+                         comoving_fac=fac if variant == "comoving" else 0.0)
+    old, g = O.gravity_finish(acc[act], G, pos=pr.ic["pos"][act],
+                              gravpm=gpm[act] if variant == "pmgrid" else None,
+                              comoving_fac=fac if variant == "comoving" else 0.0)
+    got_old, got_g = fp.get_field(B.F_OLDACC), fp.get_field(B.F_GRAVACCEL)
+    assert relerr(got_old[act], old) < 1e-15 and relerr(got_g[act], g) < 1e-15
+    rest = np.setdiff1d(np.arange(pr.n), act)
+    assert np.array_equal(got_g[rest], acc[rest]) and np.all(got_old[rest] == 0)   # inactive untouched
+
+
 def test_gravity_tree_adds_the_vacuum_energy_term_in_physical_coordinates():
     """gravtree.c:470-483: without PERIODIC and PMGRID and with ComovingIntegrationOn == 0,
     gravity_tree() adds OmegaLambda * Hubble^2 * Pos after the multiplication by G; OldAcc is the
@@ -1234,6 +1264,8 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
     treepm, multi = flavour == "treepm", flavour == "individual steps"
     comoving = flavour == "comoving"
     pr = Problem(ng=10, gas=True, periodic=1)
+    if treepm:
+        pr.G = 1.7              # GravPM carries G, the tree accelerations do not (gravtree.c:379-383)
     n, ng, box = pr.n, pr.ngas, pr.box
     typ, mass = pr.ic["type"], pr.ic["mass"]
     bin_, tb = 20, 1.0e-3 / (1 << 20)
@@ -1313,8 +1345,9 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
         else:
             acc, cost = T.gravity(pr.o_grav(theta), act, o["oldacc"])
             T.gravity_ewald_add(pr.o_grav(theta), tab, act, o["oldacc"], acc, cost)
-        o["oldacc"][act] = np.linalg.norm(acc, axis=1)
-        o["grav"][act] = pr.G * acc
+        # gravtree.c:375-403: under PMGRID OldAcc is the norm of the TOTAL acceleration
+        o["oldacc"][act], o["grav"][act] = O.gravity_finish(
+            acc, pr.G, gravpm=o_gpm[act] if treepm else None)
         if len(gas):
             od = T.density(pr.o_dens(), gas, o["velpred"], o["entropy"], o["dtentropy"],
                            o["timebin"], o["ti_begstep"], o["hsml"])
@@ -1369,7 +1402,7 @@ def test_resident_integration_loop_matches_the_oracle_loop(flavour):
         fp.density(pr.g_dens())
         fp.update_hmax()
         fp.hydro(pr.g_hydro(*hyd_args))
-        fp.gravity_finish(pr.G)
+        fp.gravity_finish_ex(pr.G, pmgrid=treepm)
         fp.advance_timesteps(_fill(B.KickParams(), par, soft),
                              kick_tables=None if tabs is None else tabs[1:])
         if pmk is not None:

@@ -406,3 +406,19 @@ def test_pm_restatement_long_range_force_of_a_point_mass():
     pos = np.vstack([src, src + 4 * rs * np.array([0.6, 0.0, 0.8])])
     a = O.pm_periodic(pos, np.array([m, 3 * m]), box, G, N)
     assert np.abs(m * a[0] + 3 * m * a[1]).max() < 1e-9 * np.abs(m * a[0]).max()
+
+
+def test_gravity_tree_post_pass_old_acc_and_g_by_hand():
+    """gravtree.c:362-403 with numbers small enough to do on paper: the G-less tree acceleration
+    (3, 0, 4), G = 2.  Plain build: OldAcc = 5, GravAccel = (6, 0, 8).  PMGRID build with
+    GravPM = (0, 24, 0) (which carries G): OldAcc = |(3, 12, 4)| = 13, GravAccel unchanged.
+    Comoving, non-periodic build without a mesh, fac = 0.5 and Pos = (2, 0, -8):
+    GravAccel -> (4, 0, 0) before OldAcc: OldAcc = 4, GravAccel = (8, 0, 0)."""
+    acc = np.array([[3.0, 0.0, 4.0]])
+    old, g = O.gravity_finish(acc, 2.0)
+    assert old[0] == 5.0 and np.array_equal(g, [[6.0, 0.0, 8.0]])
+    old, g = O.gravity_finish(acc, 2.0, gravpm=np.array([[0.0, 24.0, 0.0]]))
+    assert old[0] == 13.0 and np.array_equal(g, [[6.0, 0.0, 8.0]])
+    old, g = O.gravity_finish(acc, 2.0, pos=np.array([[2.0, 0.0, -8.0]]), comoving_fac=0.5)
+    assert old[0] == 4.0 and np.array_equal(g, [[8.0, 0.0, 0.0]])
+    assert np.array_equal(acc, [[3.0, 0.0, 4.0]])          # inputs untouched
