@@ -18,7 +18,8 @@ LIBGHIP = os.path.join(PKG_DIR, "libghip.so")
 LIBHOST = os.path.join(PKG_DIR, "libgadget_force.so")
 
 HIP_SOURCES = ["ghip_api.hip", "ghip_tree.hip", "ghip_gravity.hip", "ghip_sph.hip",
-               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip", "ghip_pm.hip"]
+               "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip", "ghip_pm.hip",
+               "ghip_dd.hip", "ghip_comm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 
@@ -40,6 +41,7 @@ def build(force=False, verbose=False):
     """Compile libghip.so (HIP, gfx950) and libgadget_force.so (host C mirror) in-tree."""
     hipcc = hipcc_path()
     hdrs = [os.path.join(CSRC, "ghip_internal.h"), os.path.join(CSRC, "ghip_walk.h"), os.path.join(CSRC, "ghip_timefac.h"),
+            os.path.join(CSRC, "ghip_keys.h"),
             os.path.join(REPO_DIR, "include", "ghip.h")]
     objs = []
     procs = []
@@ -56,7 +58,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or _newer(LIBGHIP, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lhipfft", "-o", LIBGHIP]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lhipfft", "-ldl", "-o", LIBGHIP]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -155,7 +155,11 @@ EXPORTS = [
     "ghip_drift", "ghip_gravity_finish_all", "ghip_advance_timesteps",
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
     "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
-    "ghip_gravity_vacuum_energy", "ghip_pm_kick"]
+    "ghip_gravity_vacuum_energy", "ghip_pm_kick",
+    "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
+    "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
+    "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
+    "ghip_dd_exchange_local", "ghip_dd_run", "ghip_dd_get_info"]
 
 
 def lib():
@@ -215,6 +219,21 @@ def lib():
         L.ghip_shard_count.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ghip_shard_pack.argtypes = [vp, C.c_int, vp]
         L.ghip_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ghip_dd_init.argtypes = [vp, C.c_int, C.c_int]
+        L.ghip_dd_set_domain.argtypes = [vp, vp, vp, C.c_double, vp]
+        L.ghip_dd_set_splits.argtypes = [vp, vp]
+        L.ghip_dd_keys.argtypes = [vp, vp]
+        L.ghip_dd_find_split.argtypes = [C.c_int, C.c_int, vp, vp, vp]
+        L.ghip_dd_set_ghost_margin.argtypes = [vp, C.c_double]
+        L.ghip_dd_rccl_unique_id.argtypes = [vp]
+        L.ghip_dd_rccl_connect.argtypes = [vp, vp]
+        L.ghip_dd_rccl_library.restype = C.c_char_p
+        L.ghip_dd_begin.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ghip_dd_step.argtypes = [vp]
+        L.ghip_dd_exchange.argtypes = [vp]
+        L.ghip_dd_exchange_local.argtypes = [vp, C.c_int]
+        L.ghip_dd_run.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ghip_dd_get_info.argtypes = [vp, vp]
         _LIB = L
     return _LIB
 
@@ -503,6 +522,55 @@ class ForcePath:
     def stream(self):
         return self.L.ghip_stream(self.h)
 
+    # ---- multi-GPU: domain decomposition with tree-node / ghost exchange (include/ghip.h) ----
+    def dd_init(self, rank, nranks):
+        self._chk(self.L.ghip_dd_init(self.h, int(rank), int(nranks)))
+
+    def dd_set_domain(self, corner, center, dlen, force_softening):
+        c0 = np.ascontiguousarray(corner, np.float64)
+        c1 = np.ascontiguousarray(center, np.float64)
+        so = np.ascontiguousarray(force_softening, np.float64)
+        self._chk(self.L.ghip_dd_set_domain(self.h, _ptr(c0), _ptr(c1), float(dlen), _ptr(so)))
+
+    def dd_set_splits(self, splits):
+        sp = np.ascontiguousarray(splits, np.uint64)
+        self._chk(self.L.ghip_dd_set_splits(self.h, _ptr(sp)))
+
+    def dd_keys(self):
+        out = np.zeros(self.n, np.uint64)
+        self._chk(self.L.ghip_dd_keys(self.h, _ptr(out)))
+        return out
+
+    def dd_set_ghost_margin(self, margin):
+        self._chk(self.L.ghip_dd_set_ghost_margin(self.h, float(margin)))
+
+    def dd_begin(self, op, params, walk=0):
+        self._dd_params = params          # keep the struct alive
+        self._chk(self.L.ghip_dd_begin(self.h, int(op), C.cast(C.byref(params), C.c_void_p), int(walk)))
+
+    def dd_step(self):
+        rc = self.L.ghip_dd_step(self.h)
+        if rc < 0:
+            self._chk(rc)
+        return rc
+
+    def dd_exchange(self):
+        self._chk(self.L.ghip_dd_exchange(self.h))
+
+    def dd_run(self, op, params, walk=0):
+        self._chk(self.L.ghip_dd_run(self.h, int(op), C.cast(C.byref(params), C.c_void_p), int(walk)))
+
+    def dd_rccl_connect(self, id128):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.L.ghip_dd_rccl_connect(self.h, C.cast(buf, C.c_void_p)))
+
+    def dd_info(self):
+        out = np.zeros(16, np.int64)
+        self._chk(self.L.ghip_dd_get_info(self.h, _ptr(out)))
+        keys = ("rank", "nranks", "let_imported", "let_sent", "ghosts_imported", "ghosts_sent",
+                "bytes_gravity", "bytes_density", "hsml_growth_e6", "grav_elements", "gas_elements")
+        return dict(zip(keys, (int(v) for v in out)))
+
     # ---- multi-GPU shard exchange helpers (device pointers, e.g. torch tensors' data_ptr()) ----
     def shard_count(self, gas):
         per = C.c_int(0)
@@ -515,3 +583,53 @@ class ForcePath:
 
     def shard_unpack(self, group, dev_ptr, nranks):
         self._chk(self.L.ghip_shard_unpack(self.h, int(group), C.c_void_p(dev_ptr), int(nranks)))
+
+
+# ---- multi-GPU module-level helpers ----
+DD_GRAVITY, DD_DENSITY, DD_HYDRO = 2, 3, 4
+
+
+def dd_rccl_unique_id():
+    """128 bytes of ncclGetUniqueId (rank 0 calls it, the host broadcasts them)."""
+    buf = (C.c_char * 128)()
+    rc = lib().ghip_dd_rccl_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise GhipError(rc, "ghip_dd_rccl_unique_id failed (no librccl next to the HIP runtime?)")
+    return bytes(buf)
+
+
+def dd_rccl_library():
+    return lib().ghip_dd_rccl_library().decode()
+
+
+def dd_exchange_local(paths):
+    """Run the pending exchange of several shards living in this process (ghip_dd_exchange_local)."""
+    arr = (C.c_void_p * len(paths))(*[p.h for p in paths])
+    rc = lib().ghip_dd_exchange_local(C.cast(arr, C.c_void_p), len(paths))
+    if rc != 0:
+        raise GhipError(rc, lib().ghip_last_error(paths[0].h).decode())
+
+
+def dd_run_local(paths, op, params, walk=0):
+    """One operation on all shards of this process: compute phases shard after shard, exchanges in
+    between (what ghip_dd_run does over RCCL with one shard per process)."""
+    for p, prm in zip(paths, params):
+        p.dd_begin(op, prm, walk)
+    while True:
+        rcs = [p.dd_step() for p in paths]
+        if any(r != rcs[0] for r in rcs):
+            raise RuntimeError("shards out of step: %r" % (rcs,))
+        if rcs[0] == 0:
+            return
+        dd_exchange_local(paths)
+
+
+def dd_find_split(ncpu, work):
+    """domain_findSplit_work_balanced (domain.c:1075-1113) through the library's host function."""
+    w = np.ascontiguousarray(work, np.float64)
+    start = np.zeros(ncpu, np.int32)
+    end = np.zeros(ncpu, np.int32)
+    rc = lib().ghip_dd_find_split(int(ncpu), len(w), _ptr(w), _ptr(start), _ptr(end))
+    if rc != 0:
+        raise GhipError(rc, "ghip_dd_find_split: bad arguments")
+    return start, end

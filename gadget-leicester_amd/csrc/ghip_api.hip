@@ -57,10 +57,27 @@ int ghip_join(ghip_ctx *ctx)
   return ctx ? ghip_finish_gas_tree(ctx) : GHIP_OK;
 }
 
+int *ghip_errwords(void)
+{
+  static int *words = nullptr;
+  if(!words)
+    {
+      void *p = nullptr;
+      if(hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess)
+        {
+          static int fallback[64];   // never device-visible: only reached when pinning fails
+          return fallback;
+        }
+      memset(p, 0, 256);
+      words = reinterpret_cast<int *>(p);
+    }
+  return words;
+}
+
 // call after a stream synchronisation: has a kernel reported a broken invariant?
 int ghip_check_device_errors(ghip_ctx *ctx)
 {
-  if(!ctx || !ctx->pinned)
+  if(!ctx)
     return GHIP_OK;
   static const char *what[GHIP_ERRW_COUNT] = {
     "the wavefront plan of a gravity walk exceeded its grid (ghip_walk.h, k_plan_fill)",
@@ -173,7 +190,7 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
 static void free_tree(TreeDev &t)
 {
   DevBuf *bs[] = {&t.key, &t.skey, &t.idx, &t.perm, &t.iperm, &t.cpl, &t.cnt, &t.nb,
-                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2, &t.phkey, &t.phorder};
+                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2, &t.phkey, &t.phorder, &t.slvl};
   for(DevBuf *b : bs)
     free_buf(*b);
 }
@@ -206,6 +223,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     free_buf(*b);
   free_tree(ctx->gt);
   free_tree(ctx->st);
+  ghip_dd_release(ctx);
   ghip_pm_release(ctx);
   free_buf(ctx->pm_rho);
   free_buf(ctx->pm_k);

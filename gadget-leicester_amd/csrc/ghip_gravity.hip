@@ -240,6 +240,13 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
   k.fac_intp = (p->BoxSize > 0) ? 2 * GHIP_EN / p->BoxSize : 0;
   k.debug_steps = getenv("GHIP_DEBUG_STEPS") ? 1 : 0;
+  if(ctx->dd.on)
+    {
+      // where a walk reports that it had to open an imported pruned node (d_walk_errw)
+      int *w = ghip_errword(ctx, GHIP_ERRW_LET);
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_walk_errw), &w, sizeof(w), 0, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
   // XCD-contiguous block order: off by default -- with the adaptive plan the grid is sized for
   // the worst case and its idle tail would all land on the last XCD (measured: Ewald walk 8.4 vs
   // 7.7 ms); the L2 locality it buys was within noise (12.9 vs 13.1 ms)
@@ -608,8 +615,9 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
     GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E, ctx->stream2));
 
   // OldAcc in tree order (forcetree.c:1850: aold = ErrTolForceAcc * P[target].OldAcc)
-  GCHK(ghip_gather_f64(ctx, n, P<int>(ctx->gt.perm), P<double>(ctx->f[GHIP_F_OLDACC]),
-                        P<double>(ctx->soldacc)));
+  // (multi-GPU: the tree's sources beyond the local particles are imported elements, never targets)
+  GCHK(ghip_gather_f64_lim(ctx, ctx->gt.n, P<int>(ctx->gt.perm), P<double>(ctx->f[GHIP_F_OLDACC]),
+                           n, P<double>(ctx->soldacc)));
   if(!pair)
     {
       GCHK(run_walk(ctx, A, nt, tgt, st));

@@ -16,6 +16,7 @@
 #define GHIP_NTAB 1000     // NTAB, forcetree.c:28
 #define GHIP_WAVE 64
 #define GHIP_BLOCK 256
+#define GHIP_MAXRANKS 64      // shards of a multi-GPU run (u64 rank masks)
 
 // ---------------------------------------------------------------------------------------------
 // host-side helpers
@@ -43,7 +44,97 @@ struct TreeDev
   int ns = 1;            // segments of the fine table
   int seg_ns[3] = {1, 1, 1}, seg_soff[3] = {0, 0, 0}, seg_noff[3] = {0, 0, 0};   // fine / mid / coarse
   DevBuf mq, mq2;                      // WalkHot[nelem], WalkCold[nelem]: walk records (gravity tree)
+  DevBuf slvl;                         // i32[n]: level of an imported pruned node in sorted order, 0: particle
   bool built = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU domain decomposition (ghip_dd.hip, ghip_comm.hip)
+// ---------------------------------------------------------------------------------------------
+// Target groups of a shard, two levels: DD_NSUPER super-groups of DD_NSUB groups of consecutive
+// targets along the space-filling curve.  A group is (bounding box, the least OldAcc of its
+// targets, the largest search radius); other shards test their tree nodes / gas particles against
+// these boxes to decide what this shard can possibly need (ghip_dd.hip).
+#define DD_NSUPER 32
+#define DD_NSUB 32
+#define DD_NGROUPS (DD_NSUPER * DD_NSUB)
+#define DD_TABLE (DD_NSUPER + DD_NGROUPS)   // records per shard: super-groups first
+struct __attribute__((aligned(64))) DDGroup
+{
+  double cx, cy, cz;   // box centre
+  double ex, ey, ez;   // half extents; ex < 0: empty group
+  double amin;         // gravity: least OldAcc of the targets; SPH: unused
+  double rmax;         // SPH: largest search radius (Hsml * margin) of the targets; gravity: unused
+};
+
+// one element of a locally essential tree as it crosses a link (64 B)
+struct __attribute__((aligned(64))) LetRec
+{
+  double x, y, z, m;          // particle: position, mass; pruned node: centre of mass, mass
+  unsigned long long key;     // Morton key (node: the cell's prefix, zero padded)
+  double aux;                 // particle: its softening; node: max softening below, negative = mixed
+  int level;                  // 0: particle; L > 0: node of level L that no target of the receiver opens
+  int pad;
+  double spare;
+};
+
+// a ghost gas particle as it crosses a link: the two 64-byte records of the SPH kernels
+struct __attribute__((aligned(64))) GhostRec
+{
+  double p[8];   // x, y, z, m, vx, vy, vz, h
+  double q[8];   // pressure, density, dhsmlfac, divvel, curlvel, timestep, 0, 0
+};
+
+// a pending exchange of the state machine (ghip_dd_step): executed over RCCL by ghip_dd_exchange
+// or, for several shards living in one process, by ghip_dd_exchange_local
+struct DDXchg
+{
+  int kind = 0;                 // 0 none, 1 all-gather of fixed-size blocks, 2 all-to-all-v of records
+  const void *send = nullptr;   // device
+  size_t bytes = 0;             // kind 1: bytes per rank; kind 2: bytes per record
+  DevBuf *recv = nullptr;       // kind 1: [nranks][bytes]; kind 2: records, source-rank major
+  int scount[GHIP_MAXRANKS], soff[GHIP_MAXRANKS];   // kind 2, in records (soff into `send`)
+  int rcount[GHIP_MAXRANKS], roff[GHIP_MAXRANKS];   // filled by the exchange
+  int rtotal = 0;
+};
+
+struct DDState
+{
+  bool on = false;
+  int rank = 0, nranks = 1;
+  unsigned long long splits[GHIP_MAXRANKS + 1];   // Peano-Hilbert key range of rank r: [splits[r], splits[r+1])
+  void *nccl = nullptr;                           // ncclComm_t (ghip_comm.hip)
+  // state machine
+  int op = 0, phase = 0, walk = 0;
+  ghip_grav_params gp;
+  ghip_dens_params dp;
+  ghip_hydro_params hp;
+  DDXchg x;
+  DevBuf xstage;                  // device staging of the count all-gather
+  // target-group tables: own, and everybody's after the all-gather
+  DevBuf grp_own, grp_all;        // DDGroup[DD_TABLE], DDGroup[nranks][DD_TABLE]
+  // gravity: locally essential trees
+  DevBuf reach, sendm;            // u64[nelem]: ranks whose targets reach / are sent this element
+  DevBuf selcnt;                  // i32[nranks][nblocks] block counts / offsets of the packing
+  DevBuf let_list;                // i32: per destination, the elements of this tree it is sent
+  DevBuf let_send, let_recv;      // LetRec[]
+  int let_sent = 0, gh_sent = 0;
+  double gh_growth = 0;
+  DevBuf gas_tgt;                 // i32: the local gas targets in curve order (gravity-tree indices)
+  int gt_nimp = 0;                // imported elements the next gravity-tree build includes
+  DevBuf src_x, src_y, src_z, src_m, src_aux, src_key, src_lvl;   // sources = local particles + imports
+  // SPH: ghost gas particles
+  DevBuf gh_mask;                 // u64[ngas]: ranks this gas particle is a ghost on
+  DevBuf gh_list;                 // i32: per destination, the local gas-tree indices sent (fixed for the step)
+  int gh_scount[GHIP_MAXRANKS], gh_soff[GHIP_MAXRANKS];
+  DevBuf gh_send, gh_recv;        // GhostRec[]
+  int nghost = 0;
+  double gh_margin = 1.3;         // search radii are padded by this factor when ghosts are selected
+  DevBuf gh_ratio;                // f64[2]: largest Hsml growth seen by the density iterations
+  DevBuf gsx, gsy, gsz, gsm, gsh; // gas sources = local gas + ghosts (tree build input)
+  DevBuf h0;                      // f64[ngas]: smoothing lengths the ghost selection was made with
+  // traffic of the last operation (bytes this rank sent over links, excluding its own block)
+  long long bytes_sent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct ghip_ctx
@@ -121,6 +212,7 @@ struct ghip_ctx
   DevBuf counters;
   ghip_stats stats;
   hipEvent_t ev[16];
+  DDState dd;                // multi-GPU domain decomposition (ghip_dd.hip)
   int timestep_endrun = 0;   // endrun code of the last ghip_advance_timesteps failure
   bool ev_ready = false;
 };
@@ -134,10 +226,10 @@ int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 #define GHIP_ERRW_TREE 2     // tree emission wrote outside the element list / malformed import
 #define GHIP_ERRW_GHOST 3    // spare
 #define GHIP_ERRW_COUNT 8
-static inline int *ghip_errword(ghip_ctx *ctx, int which)
-{
-  return reinterpret_cast<int *>(ctx->pinned) + 32 + which;
-}
+// (one block per process, shared by its contexts: an error raised by a kernel of one logical shard
+// is seen by whichever context synchronises next)
+int *ghip_errwords(void);
+static inline int *ghip_errword(ghip_ctx *, int which) { return ghip_errwords() + which; }
 int ghip_check_device_errors(ghip_ctx *ctx);
 // The overlapped Newton+Ewald pair returns with its walks still running on their own streams, so
 // that the SPH phases -- which read and write nothing the walks touch -- can be enqueued on the
@@ -189,7 +281,6 @@ template <class T> static inline const T *P(const DevBuf &b) { return reinterpre
 // owns buckets r, r+N, r+2N, ... (every rank samples the whole volume, so per-rank cost is
 // balanced without a cost model).  The list is stored rank-major, so a rank's targets are the
 // contiguous range [lo, lo+cnt); `per` is the padded common slice length of the all-gathers.
-#define GHIP_MAXRANKS 64
 static inline void ghip_shard_range(int nt, int nranks, int rank, int *lo, int *cnt, int *per)
 {
   int nb = (nt + 63) / 64;
@@ -218,6 +309,8 @@ int ghip_tree_build_impl(ghip_ctx *ctx);
 int ghip_build_target_lists(ghip_ctx *ctx);
 int ghip_gastree_refresh_hmax(ghip_ctx *ctx);
 int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst);
+int ghip_gather_f64_lim(ghip_ctx *ctx, int n, const int *perm, const double *src, int limit,
+                        double *dst);
 // gravity.hip
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk);
 int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records);
@@ -225,6 +318,8 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records);
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p);
 int ghip_sph_fill_nodes(ghip_ctx *ctx, bool hmax_only);
+// dd.hip
+void ghip_dd_release(ghip_ctx *ctx);
 
 // ---------------------------------------------------------------------------------------------
 // walk segments: the element list of a tree is cut into `ns` contiguous segments and `nsub`

@@ -532,7 +532,10 @@ static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
 
 static int dens_alloc(ghip_ctx *ctx)
 {
+  // (arrays indexed by gas-tree position: a multi-GPU shard's gas tree also holds its ghosts)
   size_t ng = (size_t) (ctx->ngas > 0 ? ctx->ngas : 1);
+  if((size_t) ctx->st.n > ng)
+    ng = (size_t) ctx->st.n;
   GCHK(ghip_ensure(ctx, ctx->dleft, ng * 8));
   GCHK(ghip_ensure(ctx, ctx->dright, ng * 8));
   // per-wavefront partial sums: [nsub][targets] planes

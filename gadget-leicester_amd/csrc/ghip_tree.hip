@@ -17,28 +17,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "ghip_internal.h"
-
-// ---------------------------------------------------------------------------------------------
-// keys
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long d_spread3(unsigned long long v)
-{
-  // spread the low 21 bits of v so that bit b lands at bit 3b
-  v &= 0x1fffffULL;
-  v = (v | (v << 32)) & 0x001f00000000ffffULL;
-  v = (v | (v << 16)) & 0x001f0000ff0000ffULL;
-  v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
-  v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
-  v = (v | (v << 2)) & 0x1249249249249249ULL;
-  return v;
-}
-
-// peano.c:320-333 morton_key: x is the lowest bit of each triplet
-__device__ __forceinline__ unsigned long long d_morton21(int x, int y, int z)
-{
-  return d_spread3((unsigned long long) x) | (d_spread3((unsigned long long) y) << 1) |
-         (d_spread3((unsigned long long) z) << 2);
-}
+#include "ghip_keys.h"
 
 __global__ void k_morton_from_pos(int n, const double *__restrict__ x, const double *__restrict__ y,
                                   const double *__restrict__ z, double cx, double cy, double cz,
@@ -67,65 +46,6 @@ __global__ void k_morton_from_ints(int n, const int *__restrict__ x, const int *
   if(bits < 21)
     m &= ((1ULL << (3 * bits)) - 1ULL);
   key[i] = m;
-}
-
-// peano.c:300-316 peano_hilbert_key.  The reference drives a 48-state table; the same curve is
-// generated here from its definition: base octant order ph_base (octant = 4*xbit + 2*ybit + zbit)
-// and the cube symmetry carried by each sub-cell (signed axis permutation, out[i] =
-// in[perm[i]] ^ flip[i]).  Orientation g starts as the identity; per level:
-// local = g(octant); digit = ph_base[local]; g <- child[local] o g.
-__constant__ unsigned char c_ph_base[8] = {0, 7, 1, 6, 3, 4, 2, 5};
-__constant__ unsigned char c_ph_perm[8][3] = {{0, 2, 1}, {0, 2, 1}, {2, 1, 0}, {2, 1, 0},
-                                              {0, 1, 2}, {0, 1, 2}, {2, 1, 0}, {2, 1, 0}};
-__constant__ unsigned char c_ph_flip[8][3] = {{0, 0, 0}, {0, 1, 1}, {0, 0, 0}, {1, 0, 1},
-                                              {1, 1, 0}, {1, 1, 0}, {0, 0, 0}, {1, 0, 1}};
-
-// the same curve for one 21-bit triplet (target bucketing: 64 Peano-Hilbert-consecutive particles
-// fill a box 2.7x smaller than 64 Morton-consecutive ones, so the lanes of a wavefront agree on
-// more opening decisions)
-__device__ __forceinline__ unsigned long long d_peano21(int x, int y, int z)
-{
-  int perm0 = 0, perm1 = 1, perm2 = 2, f0 = 0, f1 = 0, f2 = 0;
-  unsigned long long k = 0;
-  for(int b = GHIP_BITS - 1; b >= 0; b--)
-    {
-      int bit[3] = {(x >> b) & 1, (y >> b) & 1, (z >> b) & 1};
-      int w0 = bit[perm0] ^ f0, w1 = bit[perm1] ^ f1, w2 = bit[perm2] ^ f2;
-      int local = w0 * 4 + w1 * 2 + w2;
-      k = (k << 3) | c_ph_base[local];
-      int p[3] = {perm0, perm1, perm2}, f[3] = {f0, f1, f2};
-      int a0 = c_ph_perm[local][0], a1 = c_ph_perm[local][1], a2 = c_ph_perm[local][2];
-      perm0 = p[a0];
-      perm1 = p[a1];
-      perm2 = p[a2];
-      f0 = f[a0] ^ c_ph_flip[local][0];
-      f1 = f[a1] ^ c_ph_flip[local][1];
-      f2 = f[a2] ^ c_ph_flip[local][2];
-    }
-  return k;
-}
-
-// the leading `levels` (<= 10) digits of the same key
-__device__ __forceinline__ unsigned int d_peano_top(int x, int y, int z, int levels)
-{
-  int perm0 = 0, perm1 = 1, perm2 = 2, f0 = 0, f1 = 0, f2 = 0;
-  unsigned int k = 0;
-  for(int b = GHIP_BITS - 1; b >= GHIP_BITS - levels; b--)
-    {
-      int bit[3] = {(x >> b) & 1, (y >> b) & 1, (z >> b) & 1};
-      int w0 = bit[perm0] ^ f0, w1 = bit[perm1] ^ f1, w2 = bit[perm2] ^ f2;
-      int local = w0 * 4 + w1 * 2 + w2;
-      k = (k << 3) | c_ph_base[local];
-      int p[3] = {perm0, perm1, perm2}, f[3] = {f0, f1, f2};
-      int a0 = c_ph_perm[local][0], a1 = c_ph_perm[local][1], a2 = c_ph_perm[local][2];
-      perm0 = p[a0];
-      perm1 = p[a1];
-      perm2 = p[a2];
-      f0 = f[a0] ^ c_ph_flip[local][0];
-      f1 = f[a1] ^ c_ph_flip[local][1];
-      f2 = f[a2] ^ c_ph_flip[local][2];
-    }
-  return k;
 }
 
 __global__ void k_peano_from_ints(int n, const int *__restrict__ x, const int *__restrict__ y,
@@ -214,8 +134,11 @@ __device__ __forceinline__ int d_common_levels(unsigned long long a, unsigned lo
   return (__clzll((long long) x) - 1) / 3;
 }
 
+// slvl (multi-GPU only, else nullptr): level of source i when it is an imported pruned node
+// ("pseudo-leaf", see k_emit_elements), 0 for a particle
 __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ skey,
-                                int *__restrict__ cpl, int *__restrict__ maxlevel)
+                                const int *__restrict__ slvl, int *__restrict__ cpl,
+                                int *__restrict__ maxlevel)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int c = -1;
@@ -223,6 +146,8 @@ __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ sk
     {
       c = (i + 1 < n) ? d_common_levels(skey[i], skey[i + 1]) : -1;
       cpl[i] = c;
+      if(slvl && slvl[i] - 1 > c)
+        c = slvl[i] - 1;   // its chain of single-child ancestors reaches down to level - 1
     }
   // deepest node level of the tree = largest shared-digit count: one same-address access per
   // block of 1024 (per wavefront they cost 45 us at 5e5 particles)
@@ -245,13 +170,26 @@ __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ sk
     }
 }
 
-__global__ void k_node_counts(int n, const int *__restrict__ cpl, int *__restrict__ cnt)
+__global__ void k_node_counts(int n, const int *__restrict__ cpl, const int *__restrict__ slvl,
+                              int *__restrict__ cnt, int *__restrict__ errword)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
   int cprev = (i > 0) ? cpl[i - 1] : -1;
-  int d = cpl[i] - cprev;
+  int ceff = cpl[i];
+  if(slvl && slvl[i] > 0)
+    {
+      // a pruned node of level L stands for >= 2 particles: the cells of levels .. L-1 that hold
+      // nothing else exist too (single-child chains, like the insertion tree's).  No other source
+      // may lie inside its cell.
+      const int L = slvl[i];
+      if(cpl[i] >= L || cprev >= L)
+        *(volatile int *) errword = 3;
+      if(L - 1 > ceff)
+        ceff = L - 1;
+    }
+  int d = ceff - cprev;
   cnt[i] = d > 0 ? d : 0;
 }
 
@@ -264,13 +202,17 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
                                 const double *__restrict__ pm, const double *__restrict__ paux,
                                 double ccx, double ccy, double ccz, double dlen,
                                 double4 *__restrict__ xm, double4 *__restrict__ cl,
-                                int4 *__restrict__ lk, double *__restrict__ aux)
+                                int4 *__restrict__ lk, double *__restrict__ aux,
+                                const int *__restrict__ slvl)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
   int cprev = (i > 0) ? cpl[i - 1] : -1;
   int ci = cpl[i];
+  const int plevel = slvl ? slvl[i] : 0;   // > 0: imported pruned node (multi-GPU)
+  if(plevel > 0 && plevel - 1 > ci)
+    ci = plevel - 1;
   int base = i + nb[i];
   unsigned long long ki = skey[i];
 
@@ -333,6 +275,29 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
     }
   int pe = base + cnt[i];
   double x = px[i], y = py[i], z = pz[i];
+  if(plevel > 0)
+    {
+      // A node of another shard's tree that no target of this shard opens, imported as a leaf:
+      // its moments (centre of mass, mass, softening word) come with it, its geometry is the
+      // level-`plevel` cell of its key.  lk.y = -(level+1) - 32 keeps the moment passes off it
+      // (they address nodes by -(level+1)); every other consumer sees a node (lk.y < 0) whose
+      // skip link is e+1.
+      double len = dlen, cx = ccx, cy = ccy, cz = ccz;
+      for(int l = 1; l <= plevel; l++)
+        {
+          int digit = (int) ((ki >> (63 - 3 * l)) & 7);
+          double lenhalf = 0.25 * len;
+          cx = (digit & 1) ? cx + lenhalf : cx - lenhalf;
+          cy = (digit & 2) ? cy + lenhalf : cy - lenhalf;
+          cz = (digit & 4) ? cz + lenhalf : cz - lenhalf;
+          len = 0.5 * len;
+        }
+      lk[pe] = make_int4(pe + 1, -(plevel + 1) - 32, i, 1);
+      xm[pe] = make_double4(x, y, z, pm[i]);
+      cl[pe] = make_double4(cx, cy, cz, len);
+      aux[pe] = paux[i];
+      return;
+    }
   lk[pe] = make_int4(pe + 1, i, i, 1);
   xm[pe] = make_double4(x, y, z, pm[i]);
   cl[pe] = make_double4(x, y, z, 0.0);
@@ -462,6 +427,28 @@ __global__ void k_gather_gas(int ng, const int *__restrict__ perm, const double 
   q[5] = (double) (tb ? (1 << tb) : 0);  // hydra.c:966 timestep
   q[6] = 0;
   q[7] = 0;
+}
+
+// the same when sources beyond `limit` (imported elements of a multi-GPU tree) have no entry in src
+__global__ void k_gather_f64_lim(int n, const int *__restrict__ perm, const double *__restrict__ src,
+                                 int limit, double *__restrict__ dst)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    {
+      int i = perm[s];
+      dst[s] = i < limit ? src[i] : 0.0;
+    }
+}
+
+int ghip_gather_f64_lim(ghip_ctx *ctx, int n, const int *perm, const double *src, int limit,
+                        double *dst)
+{
+  if(n <= 0)
+    return GHIP_OK;
+  k_gather_f64_lim<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, perm, src, limit, dst);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
 }
 
 int ghip_gather_f64(ghip_ctx *ctx, int n, const int *perm, const double *src, double *dst)
@@ -676,8 +663,19 @@ static int *tree_dinfo(ghip_ctx *ctx, bool gas)
 }
 
 // Morton keys of the gravity tree's particles, sorted -> t.skey, t.perm
+// the keys imported elements carry replace the ones computed from their coordinates (a pruned
+// node's key is its cell's prefix; its centre of mass may round onto the cell's face)
+__global__ void k_override_keys(int first, int n, const unsigned long long *__restrict__ given,
+                                unsigned long long *__restrict__ key)
+{
+  int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    key[i] = given[i];
+}
+
 static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
-                       const double *z, bool wide)
+                       const double *z, bool wide, int nlocal = -1,
+                       const unsigned long long *given_keys = nullptr, bool gas = false)
 {
   hipStream_t st = ctx->stream;
   GCHK(ghip_ensure(ctx, t.key, (size_t) n * 8));
@@ -689,6 +687,9 @@ static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const 
   k_morton_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, x, y, z, ctx->corner[0], ctx->corner[1],
                                                   ctx->corner[2], fac,
                                                   P<unsigned long long>(t.key), P<int>(t.idx));
+  if(given_keys && nlocal >= 0 && nlocal < n)
+    k_override_keys<<<cdiv(n - nlocal, 256), 256, 0, st>>>(nlocal, n, given_keys,
+                                                           P<unsigned long long>(t.key));
   HIPCHK(hipGetLastError());
   size_t tb = 0;
   if(!wide)
@@ -704,7 +705,7 @@ static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const 
       k_gather_keys<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), P<unsigned long long>(t.key),
                                                   P<unsigned long long>(t.skey));
       k_fix_runs<<<cdiv(n, 256), 256, 0, st>>>(n, 32, P<unsigned long long>(t.skey),
-                                               P<int>(t.perm), tree_dinfo(ctx, false) + 1);
+                                               P<int>(t.perm), tree_dinfo(ctx, gas) + 1);
       HIPCHK(hipGetLastError());
     }
   else
@@ -741,16 +742,26 @@ static int gas_order_from_gravity_tree(ghip_ctx *ctx)
 }
 
 // common prefix levels, nodes per particle and their scan; {maxlevel, nnodes, longest run} -> hout
-static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout)
+// src_lvl (multi-GPU): levels of the imported pruned nodes in source order, gathered to sorted order
+static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout,
+                       const int *src_lvl = nullptr)
 {
   hipStream_t st = ctx->stream;
   GCHK(ghip_ensure(ctx, t.cpl, (size_t) n * 4));
   GCHK(ghip_ensure(ctx, t.cnt, (size_t) n * 4));
   GCHK(ghip_ensure(ctx, t.nb, (size_t) (n + 1) * 4));
   int *dinfo = tree_dinfo(ctx, gas);
-  k_prefix_levels<<<cdiv(n, 1024), 1024, 0, st>>>(n, P<unsigned long long>(t.skey), P<int>(t.cpl),
-                                                  dinfo);
-  k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), P<int>(t.cnt));
+  const int *slvl = nullptr;
+  if(src_lvl)
+    {
+      GCHK(ghip_ensure(ctx, t.slvl, (size_t) n * 4));
+      k_gather_i32<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), src_lvl, P<int>(t.slvl));
+      slvl = P<int>(t.slvl);
+    }
+  k_prefix_levels<<<cdiv(n, 1024), 1024, 0, st>>>(n, P<unsigned long long>(t.skey), slvl,
+                                                  P<int>(t.cpl), dinfo);
+  k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), slvl, P<int>(t.cnt),
+                                              ghip_errword(ctx, GHIP_ERRW_TREE));
   HIPCHK(hipGetLastError());
   GCHK(exclusive_sum(ctx, P<int>(t.cnt), P<int>(t.nb), n));
   k_tree_info<<<1, 1, 0, st>>>(n, P<int>(t.nb), P<int>(t.cnt), dinfo, hout);
@@ -762,7 +773,7 @@ static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout)
 static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const double *x,
                      const double *y, const double *z, const double *m, const double *aux,
                      double *ox, double *oy, double *oz, double *om, double *oa, bool grav,
-                     hipEvent_t *fork_after_gather = nullptr)
+                     hipEvent_t *fork_after_gather = nullptr, const int *slvl = nullptr)
 {
   hipStream_t st = ctx->stream;
   t.n = n;
@@ -780,7 +791,7 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
   k_emit_elements<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
     oz, om, oa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
-    P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux));
+    P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), slvl);
   HIPCHK(hipGetLastError());
   for(int L = t.maxlevel; L >= 0; L--)
     {
@@ -802,7 +813,9 @@ static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const d
 static int curve_order(ghip_ctx *ctx, hipStream_t st)
 {
   TreeDev &g = ctx->gt, &t = ctx->st;
-  int n = ctx->n, ng = ctx->ngas;
+  // (multi-GPU: the gravity tree holds imported elements too, and the shard's gas tree -- local gas
+  // plus ghosts -- gets its own order from ghip_dd.hip)
+  int n = g.n, ng = ctx->dd.on ? 0 : ctx->ngas;
   GCHK(ghip_ensure(ctx, g.phorder, (size_t) n * 4));
   if(ng > 0)
     GCHK(ghip_ensure(ctx, t.phorder, (size_t) ng * 4));
@@ -868,6 +881,42 @@ static void tree_reset(TreeDev &t, int n)
   t.built = (n == 0);
 }
 
+// sources of a multi-GPU gravity tree: the local particles followed by the imported elements
+// (ghip_dd.hip fills dd.src_* from the field arrays and the received LetRec records)
+__global__ void k_concat_sources(int n, int nimp, const double *__restrict__ x,
+                                 const double *__restrict__ y, const double *__restrict__ z,
+                                 const double *__restrict__ m, const double *__restrict__ soft,
+                                 const LetRec *__restrict__ imp, double *__restrict__ ox,
+                                 double *__restrict__ oy, double *__restrict__ oz,
+                                 double *__restrict__ om, double *__restrict__ oa,
+                                 unsigned long long *__restrict__ okey, int *__restrict__ olvl)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n + nimp)
+    return;
+  if(i < n)
+    {
+      ox[i] = x[i];
+      oy[i] = y[i];
+      oz[i] = z[i];
+      om[i] = m[i];
+      oa[i] = soft[i];
+      okey[i] = 0;
+      olvl[i] = 0;
+    }
+  else
+    {
+      const LetRec r = imp[i - n];
+      ox[i] = r.x;
+      oy[i] = r.y;
+      oz[i] = r.z;
+      om[i] = r.m;
+      oa[i] = r.aux;
+      okey[i] = r.key;
+      olvl[i] = r.level;
+    }
+}
+
 int ghip_tree_build_impl(ghip_ctx *ctx)
 {
   int n = ctx->n, ng = ctx->ngas;
@@ -875,14 +924,21 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   const double *x = P<double>(ctx->f[GHIP_F_POS]);
   const double *y = x + n, *z = y + n;
   const double *m = P<double>(ctx->f[GHIP_F_MASS]);
-  const double *h = P<double>(ctx->f[GHIP_F_HSML]);
+  // multi-GPU: the tree's sources are the local particles [0, n) plus the elements imported from
+  // the other shards [n, n + nimp); targets are local particles only.  The gas tree of a shard
+  // (local gas + ghosts) is built by ghip_dd.hip, not here.
+  const bool dd = ctx->dd.on;
+  const int nimp = dd ? ctx->dd.gt_nimp : 0;
+  const int nsrc = n + nimp;
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  tree_reset(ctx->gt, n);
-  tree_reset(ctx->st, ng);
+  tree_reset(ctx->gt, nsrc);
+  tree_reset(ctx->st, dd ? 0 : ng);
+  if(dd)
+    ctx->st.built = false;
   ctx->gas_pending = false;
   ctx->lists_dirty = true;
   ctx->stats.tree_nodes = ctx->stats.gastree_nodes = 0;
-  if(n == 0)
+  if(nsrc == 0)
     {
       HIPCHK(hipEventRecord(ctx->ev[1], st));
       return GHIP_OK;
@@ -891,23 +947,49 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
 
   // per-particle softening in host order (aux of the gravity tree's particle elements)
-  GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) n * 8));
-  GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) n * 8));
+  GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) nsrc * 8));
+  GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) nsrc * 8));
   double *tmp_soft = P<double>(ctx->soldacc);  // scratch until the first gravity call
-  k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
-                                               ctx->soft[1], ctx->soft[2], ctx->soft[3],
-                                               ctx->soft[4], ctx->soft[5],
-                                               ctx->adaptive_gravsoft ? P<double>(ctx->f[GHIP_F_HSML])
-                                                                      : nullptr,
-                                               tmp_soft);
+  if(n > 0)
+    k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
+                                                 ctx->soft[1], ctx->soft[2], ctx->soft[3],
+                                                 ctx->soft[4], ctx->soft[5],
+                                                 ctx->adaptive_gravsoft ? P<double>(ctx->f[GHIP_F_HSML])
+                                                                        : nullptr,
+                                                 tmp_soft);
+  const unsigned long long *given_keys = nullptr;
+  const int *src_lvl = nullptr;
+  if(nimp > 0)
+    {
+      DDState &D = ctx->dd;
+      GCHK(ghip_ensure(ctx, D.src_x, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_y, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_z, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_m, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_aux, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_key, (size_t) nsrc * 8));
+      GCHK(ghip_ensure(ctx, D.src_lvl, (size_t) nsrc * 4));
+      k_concat_sources<<<cdiv(nsrc, 256), 256, 0, st>>>(
+        n, nimp, x, y, z, m, tmp_soft, P<LetRec>(D.let_recv), P<double>(D.src_x), P<double>(D.src_y),
+        P<double>(D.src_z), P<double>(D.src_m), P<double>(D.src_aux),
+        P<unsigned long long>(D.src_key), P<int>(D.src_lvl));
+      HIPCHK(hipGetLastError());
+      x = P<double>(D.src_x);
+      y = P<double>(D.src_y);
+      z = P<double>(D.src_z);
+      m = P<double>(D.src_m);
+      tmp_soft = P<double>(D.src_aux);
+      given_keys = P<unsigned long long>(D.src_key);
+      src_lvl = P<int>(D.src_lvl);
+    }
 
   bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
   for(;;)
     {
       HIPCHK(hipMemsetAsync(tree_dinfo(ctx, false), 0, 16, st));
-      GCHK(sort_by_key(ctx, ctx->gt, n, x, y, z, wide));
-      GCHK(count_nodes(ctx, ctx->gt, n, false, hinfo));
-      if(ng > 0)
+      GCHK(sort_by_key(ctx, ctx->gt, nsrc, x, y, z, wide, n, given_keys));
+      GCHK(count_nodes(ctx, ctx->gt, nsrc, false, hinfo, src_lvl));
+      if(ng > 0 && !dd)
         {
           GCHK(gas_order_from_gravity_tree(ctx));
           GCHK(count_nodes(ctx, ctx->st, ng, true, hinfo + 4));
@@ -918,14 +1000,15 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       wide = true;   // strongly clustered input: long runs of equal top key bits, sort full keys
     }
 
-  GCHK(ghip_ensure(ctx, ctx->sx, (size_t) n * 8));
-  GCHK(ghip_ensure(ctx, ctx->sy, (size_t) n * 8));
-  GCHK(ghip_ensure(ctx, ctx->sz, (size_t) n * 8));
-  GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) n * 4));
-  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) n * 5 * sizeof(double)));
-  GCHK(emit_tree(ctx, ctx->gt, n, hinfo, x, y, z, m, tmp_soft, P<double>(ctx->sx),
+  GCHK(ghip_ensure(ctx, ctx->sx, (size_t) nsrc * 8));
+  GCHK(ghip_ensure(ctx, ctx->sy, (size_t) nsrc * 8));
+  GCHK(ghip_ensure(ctx, ctx->sz, (size_t) nsrc * 8));
+  GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) nsrc * 4));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsrc * 5 * sizeof(double)));
+  GCHK(emit_tree(ctx, ctx->gt, nsrc, hinfo, x, y, z, m, tmp_soft, P<double>(ctx->sx),
                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->stage),
-                 P<double>(ctx->ssoft), true, &ctx->evt[0]));
+                 P<double>(ctx->ssoft), true, &ctx->evt[0],
+                 src_lvl ? P<int>(ctx->gt.slvl) : nullptr));
   ctx->gt.built = true;
   // The curve order of the targets needs the tree-order positions only (the gather at the head of
   // emit_tree): it runs on a second stream next to the element emission, the moment passes and the
@@ -943,7 +1026,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   // counts and curve order are known; the rest of its build is deferred to the first call that
   // needs it (ghip_finish_gas_tree), which normally is ghip_density -- enqueued while a gravity
   // pair is in flight, so that this work runs underneath the walks.
-  if(ng > 0)
+  if(ng > 0 && !dd)
     {
       for(int q = 0; q < 3; q++)
         ctx->gas_hinfo[q] = hinfo[4 + q];
@@ -956,6 +1039,194 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   ctx->stats.tree_nodes = ctx->gt.nnodes;
   ctx->stats.gastree_nodes = ctx->st.nnodes;
   return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: the gas tree of a shard = its own gas particles [0, ngas) + the ghosts imported from
+// the other shards [ngas, ngas + nghost) (ghip_dd.hip).  Ghosts are sources only.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_concat_gas_sources(int ng, int nghost, int n, const double *__restrict__ pos,
+                                     const double *__restrict__ mass, const double *__restrict__ h,
+                                     const GhostRec *__restrict__ gh, double *__restrict__ ox,
+                                     double *__restrict__ oy, double *__restrict__ oz,
+                                     double *__restrict__ om, double *__restrict__ oh)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= ng + nghost)
+    return;
+  if(i < ng)
+    {
+      ox[i] = pos[i];
+      oy[i] = pos[(size_t) n + i];
+      oz[i] = pos[2 * (size_t) n + i];
+      om[i] = mass[i];
+      oh[i] = h[i];
+    }
+  else
+    {
+      const GhostRec &r = gh[i - ng];
+      ox[i] = r.p[0];
+      oy[i] = r.p[1];
+      oz[i] = r.p[2];
+      om[i] = r.p[3];
+      oh[i] = r.p[7];
+    }
+}
+
+// the ghosts' records (gp, gq) in gas-tree order, straight from the received GhostRec
+__global__ void k_place_ghosts(int nsrc, int ng, const int *__restrict__ perm,
+                               const GhostRec *__restrict__ gh, double *__restrict__ gp,
+                               double *__restrict__ gq)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= nsrc)
+    return;
+  const int i = perm[s];
+  if(i < ng)
+    return;
+  const GhostRec &r = gh[i - ng];
+  for(int c = 0; c < 8; c++)
+    {
+      gp[(size_t) 8 * s + c] = r.p[c];
+      gq[(size_t) 8 * s + c] = r.q[c];
+    }
+}
+
+// k_gather_gas for the local part of a shard's gas tree (sources >= ng are ghosts)
+__global__ void k_gather_gas_local(int nsrc, int ng, const int *__restrict__ perm,
+                                   const double *__restrict__ x, const double *__restrict__ y,
+                                   const double *__restrict__ z, const double *__restrict__ m,
+                                   const double *__restrict__ vx, const double *__restrict__ vy,
+                                   const double *__restrict__ vz, const double *__restrict__ h,
+                                   const double *__restrict__ pres, const double *__restrict__ rho,
+                                   const double *__restrict__ dhf, const double *__restrict__ divv,
+                                   const double *__restrict__ curl, const int *__restrict__ timebin,
+                                   double *__restrict__ gp, double *__restrict__ gq)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= nsrc)
+    return;
+  int i = perm[s];
+  if(i >= ng)
+    return;
+  double *r = gp + (size_t) 8 * s;
+  r[0] = x[i];
+  r[1] = y[i];
+  r[2] = z[i];
+  r[3] = m[i];
+  r[4] = vx[i];
+  r[5] = vy[i];
+  r[6] = vz[i];
+  r[7] = h[i];
+  double *q = gq + (size_t) 8 * s;
+  int tb = timebin[i];
+  q[0] = pres[i];
+  q[1] = rho[i];
+  q[2] = dhf[i];
+  q[3] = divv[i];
+  q[4] = curl[i];
+  q[5] = (double) (tb ? (1 << tb) : 0);  // hydra.c:966 timestep
+  q[6] = 0;
+  q[7] = 0;
+}
+
+int ghip_dd_build_gas_tree(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  const int n = ctx->n, ng = ctx->ngas, nghost = D.nghost, nsg = ng + nghost;
+  hipStream_t st = ctx->stream;
+  TreeDev &t = ctx->st;
+  tree_reset(t, nsg);
+  ctx->gas_pending = false;
+  ctx->lists_dirty = true;
+  ctx->stats.gastree_nodes = 0;
+  if(nsg == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, D.gsx, (size_t) nsg * 8));
+  GCHK(ghip_ensure(ctx, D.gsy, (size_t) nsg * 8));
+  GCHK(ghip_ensure(ctx, D.gsz, (size_t) nsg * 8));
+  GCHK(ghip_ensure(ctx, D.gsm, (size_t) nsg * 8));
+  GCHK(ghip_ensure(ctx, D.gsh, (size_t) nsg * 8));
+  double *gx = P<double>(D.gsx), *gy = P<double>(D.gsy), *gz = P<double>(D.gsz),
+         *gm = P<double>(D.gsm), *gh = P<double>(D.gsh);
+  k_concat_gas_sources<<<cdiv(nsg, 256), 256, 0, st>>>(
+    ng, nghost, n, P<double>(ctx->f[GHIP_F_POS]), P<double>(ctx->f[GHIP_F_MASS]),
+    P<double>(ctx->f[GHIP_F_HSML]), P<GhostRec>(D.gh_recv), gx, gy, gz, gm, gh);
+  HIPCHK(hipGetLastError());
+  int *hinfo = reinterpret_cast<int *>(ctx->pinned) + 4;
+  bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
+  for(;;)
+    {
+      HIPCHK(hipMemsetAsync(tree_dinfo(ctx, true), 0, 8, st));
+      GCHK(sort_by_key(ctx, t, nsg, gx, gy, gz, wide, -1, nullptr, true));
+      GCHK(count_nodes(ctx, t, nsg, true, hinfo));
+      HIPCHK(hipStreamSynchronize(st));
+      if(wide || hinfo[2] == 0)
+        break;
+      wide = true;
+    }
+  GCHK(ghip_ensure(ctx, t.iperm, (size_t) nsg * 4));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsg * 5 * sizeof(double)));
+  double *s = P<double>(ctx->stage);
+  GCHK(emit_tree(ctx, t, nsg, hinfo, gx, gy, gz, gm, gh, s, s + nsg, s + 2 * (size_t) nsg,
+                 s + 3 * (size_t) nsg, s + 4 * (size_t) nsg, false));
+  t.built = true;
+  GCHK(ghip_sph_fill_nodes(ctx, false));
+  GCHK(ghip_ensure(ctx, ctx->gp, (size_t) nsg * 64));
+  GCHK(ghip_ensure(ctx, ctx->gq, (size_t) nsg * 64));
+  const double *x = P<double>(ctx->f[GHIP_F_POS]);
+  const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
+  if(ng > 0)
+    k_gather_gas_local<<<cdiv(nsg, 256), 256, 0, st>>>(
+      nsg, ng, P<int>(t.perm), x, x + n, x + 2 * (size_t) n, P<double>(ctx->f[GHIP_F_MASS]), vp,
+      vp + ng, vp + 2 * (size_t) ng, P<double>(ctx->f[GHIP_F_HSML]),
+      P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
+      P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
+      P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
+      P<double>(ctx->gq));
+  if(nghost > 0)
+    k_place_ghosts<<<cdiv(nsg, 256), 256, 0, st>>>(nsg, ng, P<int>(t.perm), P<GhostRec>(D.gh_recv),
+                                                  P<double>(ctx->gp), P<double>(ctx->gq));
+  HIPCHK(hipGetLastError());
+  // curve order of the sources (the targets are selected from it): leading digits of the
+  // Peano-Hilbert key of the tree-order positions, as curve_order does for the gravity tree
+  GCHK(ghip_ensure(ctx, t.phorder, (size_t) nsg * 4));
+  int levels = 3;
+  for(long long m = nsg; m > 1; m >>= 3)
+    levels++;
+  if(levels > 10)
+    levels = 10;
+  const double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);
+  unsigned int *hi_in = P<unsigned int>(t.phkey), *hi_out = hi_in + nsg;
+  k_peano_hi<<<cdiv(nsg, 256), 256, 0, st>>>(nsg, levels, s, s + nsg, s + 2 * (size_t) nsg,
+                                             ctx->corner[0], ctx->corner[1], ctx->corner[2], fac,
+                                             hi_in, P<int>(t.idx));
+  HIPCHK(hipGetLastError());
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(t.idx),
+                                            P<int>(t.phorder), nsg, 0, 3 * levels, st));
+  GCHK(cub_tmp(ctx, tb));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(t.idx),
+                                            P<int>(t.phorder), nsg, 0, 3 * levels, st));
+  ctx->stats.gastree_nodes = t.nnodes;
+  return GHIP_OK;
+}
+
+// the ghosts' records as their owners hold them after density() (same order as the first import)
+int ghip_dd_refresh_ghosts(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  TreeDev &t = ctx->st;
+  if(!t.built)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghost refresh without a gas tree");
+  if(D.nghost > 0)
+    {
+      k_place_ghosts<<<cdiv(t.n, 256), 256, 0, ctx->stream>>>(t.n, ctx->ngas, P<int>(t.perm),
+                                                             P<GhostRec>(D.gh_recv),
+                                                             P<double>(ctx->gp), P<double>(ctx->gq));
+      HIPCHK(hipGetLastError());
+    }
+  return ghip_gastree_refresh_hmax(ctx);
 }
 
 int ghip_finish_gas_tree(ghip_ctx *ctx)
@@ -1020,6 +1291,14 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
   return GHIP_OK;
 }
 
+// flags of the tree-order sources that are local particles (multi-GPU)
+__global__ void k_flag_local(int n, int limit, const int *__restrict__ perm, int *__restrict__ flags)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    flags[s] = perm[s] < limit ? 1 : 0;
+}
+
 // target lists: tree-order positions of the active particles, ascending (so that 64
 // consecutive targets are spatial neighbours), sliced for this rank's shard
 static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, int *count)
@@ -1030,7 +1309,8 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
   if(n == 0)
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, list, (size_t) n * 4));
-  if(ctx->nactive < 0)
+  const bool imports = n > host_limit;   // multi-GPU: sources beyond the local particles are never targets
+  if(ctx->nactive < 0 && !imports)
     {
       HIPCHK(hipMemcpyAsync(list.p, t.phorder.p, (size_t) n * 4, hipMemcpyDeviceToDevice, st));
       *count = n;
@@ -1040,10 +1320,15 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
   GCHK(ghip_ensure(ctx, ctx->dtgt_a, (size_t) n * 4 + 16));
-  HIPCHK(hipMemsetAsync(ctx->dflags.p, 0, (size_t) n * 4, st));
-  k_mark_active<<<cdiv(ctx->nactive, 256), 256, 0, st>>>(ctx->nactive, P<int>(ctx->act_host_idx),
-                                                          P<int>(t.iperm), host_limit,
-                                                          P<int>(ctx->dflags));
+  if(ctx->nactive < 0)
+    k_flag_local<<<cdiv(n, 256), 256, 0, st>>>(n, host_limit, P<int>(t.perm), P<int>(ctx->dflags));
+  else
+    {
+      HIPCHK(hipMemsetAsync(ctx->dflags.p, 0, (size_t) n * 4, st));
+      k_mark_active<<<cdiv(ctx->nactive, 256), 256, 0, st>>>(ctx->nactive, P<int>(ctx->act_host_idx),
+                                                              P<int>(t.iperm), host_limit,
+                                                              P<int>(ctx->dflags));
+    }
   // flags in Peano-Hilbert order, then an order-preserving selection of the PH-ordered indices
   k_gather_i32<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.phorder), P<int>(ctx->dflags),
                                              P<int>(ctx->dtgt_a));
@@ -1109,7 +1394,10 @@ int ghip_build_target_lists(ghip_ctx *ctx)
   if(ctx->nactive >= 0)
     GCHK(ghip_finish_gas_tree(ctx));   // an active subset is marked through st.iperm
   GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
-  GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
+  if(ctx->dd.on && !ctx->st.built)
+    ctx->nt_gas = 0;   // multi-GPU: the gas list is made when the shard's gas tree exists (ghip_dd.hip)
+  else
+    GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
   GCHK(permute_for_shards(ctx, ctx->tg_grav, ctx->nt_grav));
   GCHK(permute_for_shards(ctx, ctx->tg_gas, ctx->nt_gas));
   ctx->lists_dirty = false;

@@ -49,6 +49,11 @@ struct GravK
   double fac_intp;     // ewald: 2*EN/BoxSize
 };
 
+// multi-GPU: the device error word (pinned host memory) a wavefront sets when a lane has to open an
+// imported pruned node.  A device-side pointer, not a kernel argument: it is read only on that
+// (never taken) path, so the walk loop carries no register for it.
+__device__ int *d_walk_errw = nullptr;
+
 // hot half of an element (64 B):  x, y, z, mass | (mass*len)*len, len*len | skip, pidx | aux
 //   node: centre of mass, opening-criterion operands in the reference's operation order
 //   (forcetree.c:2085), aux = max softening below (negative: mixed softenings)
@@ -411,7 +416,17 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
       interact = act & ~drop & ~open;
       if(D_LANE(interact | drop))
         my_skip = skip;
-      next = (open != 0) ? e + 1 : skip;
+      next = skip;
+      if(open != 0)
+        {
+          next = e + 1;
+          // multi-GPU: a node imported from another shard as a leaf (skip == e + 1: nothing below
+          // it came along) must never be opened -- the sender proved that no target here can.  If
+          // one does, the locally essential tree was incomplete: hard error, not silently lost
+          // mass.  (A cell of this shard's own holds >= 2 particles: its skip is >= e + 3.)
+          if(skip == next && d_walk_errw)
+            *(volatile int *) d_walk_errw = 1;
+        }
     }
 
   if(OWNED && D_LANE(interact))

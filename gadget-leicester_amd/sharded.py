@@ -1,4 +1,18 @@
-"""One force step sharded over the GPUs of a node (one process per GPU, torch.distributed).
+"""Force steps sharded over the GPUs of a node (one process per GPU).
+
+Two modes:
+
+* DOMAIN DECOMPOSITION (default; `decompose`, `DomainShards`, `DomainRank` below): every shard
+  owns the particles of one Peano-Hilbert key range; tree nodes (locally essential trees) and
+  ghost gas particles cross the links, in C over RCCL (ghip_dd_* in include/ghip.h).  This module
+  only cuts the curve (`decompose`, calling the library's restatement of
+  domain_findSplit_work_balanced) and drives the per-operation state machine.
+
+* REPLICATED SOURCES (`ShardedForceStep`, the round-1 design, kept selectable): every rank holds
+  all particles, targets are dealt out in buckets, results are all-gathered by torch.distributed.
+
+----- replicated mode -----
+One force step sharded over the GPUs of a node (one process per GPU, torch.distributed).
 
 Replaces the reference's MPI export/import rounds (gravtree.c:175-339, density.c:193-389,
 hydra.c:274-526).  Design ("Multi-GPU"): every rank holds all particles and builds
@@ -104,3 +118,99 @@ class ShardedForceStep:
             e.set_shard(0, 1)
             e.gravity_finish(G)
             e.set_shard(self.rank, self.world)
+
+
+# ================================================================================================
+# domain decomposition
+# ================================================================================================
+import importlib as _importlib
+
+import numpy as _np
+
+
+def _bindings():
+    return _importlib.import_module(__package__ + ".bindings")
+
+
+def histogram_level(n):
+    """Level of the key histogram the curve is cut on: about 32 particles per cell, 8^level cells,
+    level in 1..7 (the reference refines its top-tree until a leaf holds few particles,
+    domain.c:1738-1960; a fixed level is enough for the sizes of BASELINE's configs)."""
+    level = 1
+    while level < 7 and 8 ** level * 32 < n:
+        level += 1
+    return level
+
+
+def decompose(keys, nranks, work=None, level=None):
+    """Cut the Peano-Hilbert curve into `nranks` contiguous ranges of about equal work.
+    keys: uint64 Peano-Hilbert keys (21 bits per dimension) of ALL particles; work: per-particle
+    cost, the reference's (1 + GravCost) / 2^TimeBin (domain.c:378-384), default 1.
+    The work is summed per level-`level` cell and the cells are cut by the library's
+    ghip_dd_find_split = domain_findSplit_work_balanced (domain.c:1075-1113).
+    Returns (splits[nranks+1] uint64, owner[n] int)."""
+    keys = _np.ascontiguousarray(keys, _np.uint64)
+    n = len(keys)
+    if level is None:
+        level = histogram_level(n)
+    while 8 ** level < nranks:
+        level += 1
+    shift = _np.uint64(63 - 3 * level)
+    cell = (keys >> shift).astype(_np.int64)
+    w = _np.ones(n) if work is None else _np.asarray(work, _np.float64)
+    hist = _np.bincount(cell, weights=w, minlength=8 ** level)
+    start, end = _bindings().dd_find_split(nranks, hist)
+    splits = _np.zeros(nranks + 1, _np.uint64)
+    for r in range(nranks):
+        splits[r] = _np.uint64(int(start[r])) << shift
+    splits[0] = 0
+    splits[nranks] = _np.uint64(1) << _np.uint64(63)
+    owner = _np.searchsorted(splits[1:nranks], keys, side="right").astype(_np.int32)
+    return splits, owner
+
+
+class DomainShards:
+    """All shards of a run as contexts of THIS process (one after the other on one GPU, or one per
+    visible GPU): the parity-test and rehearsal form of the multi-GPU path.  Exchanges are
+    device-to-device copies (ghip_dd_exchange_local); everything else is the code the RCCL path
+    runs."""
+
+    def __init__(self, paths):
+        self.paths = list(paths)
+        self.B = _bindings()
+
+    def run(self, op, params, walk=0):
+        prm = params if isinstance(params, (list, tuple)) else [params] * len(self.paths)
+        self.B.dd_run_local(self.paths, op, prm, walk)
+
+    def gravity(self, params, walk):
+        self.run(self.B.DD_GRAVITY, params, walk)
+
+    def density(self, params):
+        self.run(self.B.DD_DENSITY, params)
+
+    def hydro(self, params):
+        self.run(self.B.DD_HYDRO, params)
+
+
+class DomainRank:
+    """One shard per process over RCCL.  `bcast(obj_or_None)` is the host's broadcast from rank 0
+    (MPI_Bcast in the reference's world, torch.distributed.broadcast_object_list in bench.py): it
+    carries the 128-byte RCCL id once."""
+
+    def __init__(self, path, rank, nranks, bcast):
+        self.p, self.rank, self.nranks = path, int(rank), int(nranks)
+        self.B = _bindings()
+        path.dd_init(rank, nranks)
+        uid = self.B.dd_rccl_unique_id() if rank == 0 else None
+        uid = bcast(uid)
+        path.dd_rccl_connect(uid)
+
+    def gravity(self, params, walk):
+        self.p.dd_run(self.B.DD_GRAVITY, params, walk)
+
+    def density(self, params):
+        self.p.dd_run(self.B.DD_DENSITY, params)
+
+    def hydro(self, params):
+        self.p.dd_run(self.B.DD_HYDRO, params)

@@ -270,6 +270,62 @@ int ghip_shard_count(ghip_ctx *ctx, int gas, int *per, int *mine);
 int ghip_shard_pack(ghip_ctx *ctx, int group, void *dev_buf);
 int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_all, int nranks);
 
+/* ---- multi-GPU: Peano-Hilbert domain decomposition with tree-node / ghost exchange ----
+ * One process (or, for tests, one context) per GPU; each holds the particles of ONE contiguous
+ * Peano-Hilbert key range (domain.c:100 domain_Decomposition; ranges cut by cumulative work,
+ * domain.c:378-384, 1075-1113).  Replaces the top-tree pseudo-particles of force_treebuild
+ * (forcetree.c:384-450, 879-1075) and the export rounds of gravity_tree / density / hydro_force
+ * (gravtree.c:175-339, density.c:193-389, hydra.c:274-526):
+ *   gravity  every shard receives, once per call, the part of every other shard's tree that its
+ *            targets can possibly open (a locally essential tree: particles + pruned nodes with
+ *            their moments), builds ONE tree over its particles and the imports and walks it --
+ *            per target the opening decisions, hence GravCost, equal the single-rank tree's;
+ *   SPH      gas particles within the padded search radius of another shard's targets (or whose own
+ *            smoothing sphere reaches them) are imported as ghosts before density(); their records
+ *            are refreshed once between density() and hydro_force().
+ * Results of a shard cover its own (active) particles only; nothing is replicated.
+ *
+ * An operation is a small state machine, so that the same code serves RCCL (one rank per process)
+ * and several logical shards in one process (parity tests on one GPU):
+ *   ghip_dd_begin(op)   then   while(ghip_dd_step() == 1) <exchange>
+ * where <exchange> is ghip_dd_exchange (this rank's part of a collective over RCCL: ncclAllGather,
+ * or ncclAllGather of counts + grouped ncclSend/ncclRecv) or ghip_dd_exchange_local (all shards of
+ * one process at once, device-to-device copies).  ghip_dd_run = the whole loop over RCCL. */
+#define GHIP_DD_GRAVITY 2    /* params: ghip_grav_params, walk: GHIP_WALK_*; tree build included */
+#define GHIP_DD_DENSITY 3    /* params: ghip_dens_params; needs the gravity tree of this step */
+#define GHIP_DD_HYDRO 4      /* params: ghip_hydro_params; after GHIP_DD_DENSITY + ghip_update_hmax */
+int ghip_dd_init(ghip_ctx *ctx, int rank, int nranks);
+/* the global domain cube (identical on all ranks: the all-reduced extent of domain_findExtent,
+ * domain.c:1972-2014) and All.ForceSoftening -- what ghip_tree_build takes in a single-GPU run */
+int ghip_dd_set_domain(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
+                       double DomainLen, const double ForceSoftening[6]);
+/* nranks+1 Peano-Hilbert keys (21 bits per dimension): rank r owns [splits[r], splits[r+1]);
+ * splits[0] = 0, splits[nranks] = 2^63.  Every resident particle must lie in its rank's range. */
+int ghip_dd_set_splits(ghip_ctx *ctx, const unsigned long long *splits);
+/* Peano-Hilbert keys of the resident particles (host array of numpart entries) */
+int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host);
+/* domain_findSplit_work_balanced (domain.c:1075-1113, equal speed factors): cut ndomain
+ * curve-ordered pieces of work into ncpu contiguous ranges [start[i], end[i]].  Host arithmetic. */
+int ghip_dd_find_split(int ncpu, int ndomain, const double *domainWork, int *start, int *end);
+/* search radii are padded by this factor when ghosts are selected (default 1.3); a density() whose
+ * h iteration leaves the padded radius fails with GHIP_EDEVICE */
+int ghip_dd_set_ghost_margin(ghip_ctx *ctx, double margin);
+/* RCCL: rank 0 creates the id (128 bytes) and the host broadcasts it (MPI_Bcast in the reference's
+ * world); every rank then connects.  The library binds the librccl that sits next to the HIP
+ * runtime the process uses (ghip_dd_rccl_library tells which). */
+int ghip_dd_rccl_unique_id(void *id128);
+int ghip_dd_rccl_connect(ghip_ctx *ctx, const void *id128);
+const char *ghip_dd_rccl_library(void);
+int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk);
+int ghip_dd_step(ghip_ctx *ctx);                 /* 1: exchange pending, 0: done, < 0: error */
+int ghip_dd_exchange(ghip_ctx *ctx);             /* RCCL */
+int ghip_dd_exchange_local(ghip_ctx **ctxs, int nranks);
+int ghip_dd_run(ghip_ctx *ctx, int op, const void *params, int walk);
+/* out[0..10]: rank, nranks, elements imported into the gravity tree, elements sent, ghosts
+ * imported, ghosts sent, bytes sent by the last gravity / density operation, largest Hsml growth
+ * of the last density (x 1e6), elements of the gravity / gas tree */
+int ghip_dd_get_info(const ghip_ctx *ctx, long long out[16]);
+
 /* ---- pre-condition of the path: drift the resident particles (replaces the lazy
  * drift_particle() calls inside the walks, forcetree.c:1911, ngb.c:57) ---- */
 int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p);

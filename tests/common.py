@@ -140,3 +140,84 @@ def relerr(a, b):
         return float(np.max(np.abs(a - b) / den)) if len(a) else 0.0
     den = np.maximum(np.linalg.norm(b, axis=1), 1e-300)
     return float(np.max(np.linalg.norm(a - b, axis=1) / den)) if len(a) else 0.0
+
+
+class ShardSet:
+    """A Problem cut into `nshards` Peano-Hilbert key ranges, each resident in a device context of
+    its own (several logical shards on one GPU): the multi-GPU path as the parity tests drive it.
+    Local particle order of a shard: its gas particles first (allvars.h:1384), global order kept."""
+
+    def __init__(self, pr, nshards, work=None, dev=0, fields=None):
+        B = bindings()
+        sh = importlib.import_module("gadget-leicester_amd.sharded")
+        self.pr, self.P, self.B = pr, nshards, B
+        ic = pr.ic
+        # keys from the device (ghip_dd_keys), checked against the oracle's table-driven curve
+        probe = B.ForcePath(dev)
+        probe.set_counts(pr.n, 0)
+        probe.set_field(B.F_POS, ic["pos"])
+        probe.dd_init(0, 1)
+        probe.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+        self.keys = probe.dd_keys()
+        probe.close()
+        fac = (1 << 21) / pr.extent[2]
+        ip = ((ic["pos"] - pr.extent[0]) * fac).astype(np.int64)
+        sample = np.arange(0, pr.n, max(1, pr.n // 512))
+        want = np.array([O.peano_hilbert_key(*ip[i]) for i in sample], dtype=np.uint64)
+        assert np.array_equal(self.keys[sample], want), "device Peano-Hilbert keys differ"
+        self.splits, self.owner = sh.decompose(self.keys, nshards, work)
+        self.gid, self.ngas, self.fp = [], [], []
+        extra = fields or {}
+        for r in range(nshards):
+            mine = np.where(self.owner == r)[0]
+            g = np.concatenate([mine[mine < pr.ngas], mine[mine >= pr.ngas]]).astype(np.int64)
+            ngl = int((mine < pr.ngas).sum())
+            self.gid.append(g)
+            self.ngas.append(ngl)
+            fp = B.ForcePath(dev)
+            fp.set_counts(len(g), ngl)
+            if len(g):
+                fp.set_field(B.F_POS, ic["pos"][g])
+                fp.set_field(B.F_VEL, ic["vel"][g])
+                fp.set_field(B.F_MASS, ic["mass"][g])
+                fp.set_field(B.F_TYPE, ic["type"][g])
+                fp.set_field(B.F_HSML, extra.get("hsml", pr.hsml0)[g])
+                fp.set_field(B.F_TIMEBIN, pr.timebin[g])
+                fp.set_field(B.F_TI_BEGSTEP, pr.ti_begstep[g])
+                fp.set_field(B.F_OLDACC, extra.get("oldacc", np.zeros(pr.n))[g])
+            if ngl:
+                gg = g[:ngl]
+                fp.set_field(B.F_VELPRED, pr.velpred[gg])
+                fp.set_field(B.F_ENTROPY, pr.entropy[gg])
+                fp.set_field(B.F_DTENTROPY, pr.dtentropy[gg])
+            fp.dd_init(r, nshards)
+            fp.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+            fp.dd_set_splits(self.splits)
+            self.fp.append(fp)
+        self.run = sh.DomainShards(self.fp)
+
+    def set_field(self, field, glob):
+        gas = self.B._FIELD_INFO[field][0]
+        for r, fp in enumerate(self.fp):
+            g = self.gid[r][:self.ngas[r]] if gas else self.gid[r]
+            if len(g):
+                fp.set_field(field, np.asarray(glob)[g])
+
+    def get_field(self, field):
+        B = self.B
+        gas, ncomp, isint = B._FIELD_INFO[field]
+        nglob = self.pr.ngas if gas else self.pr.n
+        shape = (nglob, 3) if ncomp == 3 else (nglob,)
+        out = np.zeros(shape, np.int32 if isint else np.float64)
+        for r, fp in enumerate(self.fp):
+            g = self.gid[r][:self.ngas[r]] if gas else self.gid[r]
+            if len(g):
+                out[g] = fp.get_field(field)
+        return out
+
+    def each(self, fn):
+        return [fn(fp) for fp in self.fp]
+
+    def close(self):
+        for fp in self.fp:
+            fp.close()
