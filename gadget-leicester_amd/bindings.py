@@ -13,7 +13,7 @@ _pkg = importlib.import_module(__package__)
 # enum ghip_field
 (F_POS, F_VEL, F_MASS, F_TYPE, F_OLDACC, F_HSML, F_TIMEBIN, F_TI_BEGSTEP, F_VELPRED, F_ENTROPY,
  F_DTENTROPY, F_GRAVACCEL, F_GRAVCOST, F_NUMNGB, F_DENSITY, F_DHSMLFAC, F_DIVVEL, F_CURLVEL,
- F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_TI_CURRENT, F_GRAVPM, F_COUNT) = range(24)
+ F_PRESSURE, F_HYDROACCEL, F_MAXSIGNALVEL, F_TI_CURRENT, F_GRAVPM, F_ID, F_COUNT) = range(25)
 
 _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_POS: (0, 3, 0), F_VEL: (0, 3, 0), F_MASS: (0, 1, 0), F_TYPE: (0, 1, 1), F_OLDACC: (0, 1, 0),
@@ -21,7 +21,7 @@ _FIELD_INFO = {  # gas-sized?, ncomp, is int
     F_ENTROPY: (1, 1, 0), F_DTENTROPY: (1, 1, 0), F_GRAVACCEL: (0, 3, 0), F_GRAVCOST: (0, 1, 1),
     F_NUMNGB: (1, 1, 0), F_DENSITY: (1, 1, 0), F_DHSMLFAC: (1, 1, 0), F_DIVVEL: (1, 1, 0),
     F_CURLVEL: (1, 1, 0), F_PRESSURE: (1, 1, 0), F_HYDROACCEL: (1, 3, 0), F_MAXSIGNALVEL: (1, 1, 0),
-    F_TI_CURRENT: (0, 1, 1), F_GRAVPM: (0, 3, 0)}
+    F_TI_CURRENT: (0, 1, 1), F_GRAVPM: (0, 3, 0), F_ID: (0, 1, 1)}
 
 WALK_NEWTON, WALK_SHORTRANGE, WALK_EWALD, WALK_NEWTON_EWALD = 0, 1, 2, 3
 EN = 64
@@ -143,6 +143,9 @@ class GhipError(RuntimeError):
 
 _LIB = None
 
+# int allgather(void *user, const void *send, size_t bytes, void *recv)
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
 EXPORTS = [
     "ghip_create", "ghip_destroy", "ghip_last_error", "ghip_version", "ghip_set_counts",
     "ghip_set_field", "ghip_get_field", "ghip_upload_aos", "ghip_download_aos", "ghip_set_active",
@@ -159,7 +162,7 @@ EXPORTS = [
     "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
     "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
-    "ghip_dd_exchange_local", "ghip_dd_run", "ghip_dd_get_info"]
+    "ghip_dd_exchange_local", "ghip_dd_exchange_host", "ghip_dd_run", "ghip_dd_get_info"]
 
 
 def lib():
@@ -233,6 +236,7 @@ def lib():
         L.ghip_dd_exchange.argtypes = [vp]
         L.ghip_dd_exchange_local.argtypes = [vp, C.c_int]
         L.ghip_dd_run.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ghip_dd_exchange_host.argtypes = [vp, ALLGATHER_CB, vp]
         L.ghip_dd_get_info.argtypes = [vp, vp]
         _LIB = L
     return _LIB
@@ -546,7 +550,15 @@ class ForcePath:
 
     def dd_begin(self, op, params, walk=0):
         self._dd_params = params          # keep the struct alive
-        self._chk(self.L.ghip_dd_begin(self.h, int(op), C.cast(C.byref(params), C.c_void_p), int(walk)))
+        ptr = None if params is None else C.cast(C.byref(params), C.c_void_p)
+        self._chk(self.L.ghip_dd_begin(self.h, int(op), ptr, int(walk)))
+
+    def counts(self):
+        """(numpart, ngas) of the context -- they change when particles migrate"""
+        out = np.zeros(16, np.int64)
+        self._chk(self.L.ghip_dd_get_info(self.h, _ptr(out)))
+        self.n, self.ngas = int(out[11]), int(out[12])
+        return self.n, self.ngas
 
     def dd_step(self):
         rc = self.L.ghip_dd_step(self.h)
@@ -557,8 +569,34 @@ class ForcePath:
     def dd_exchange(self):
         self._chk(self.L.ghip_dd_exchange(self.h))
 
+    def dd_run_host(self, op, params, allgather, walk=0):
+        """The operation with every exchange staged through the host and `allgather(send: bytes)
+        -> bytes of all ranks, rank-major` (ghip_dd_exchange_host)."""
+        def cb(_user, send, nbytes, recv):
+            try:
+                data = C.string_at(send, nbytes)
+                out = allgather(data)
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:   # noqa: BLE001 -- reported through the C return code
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = ALLGATHER_CB(cb)
+        self.dd_begin(op, params, walk)
+        while True:
+            rc = self.dd_step()
+            if rc == 0:
+                break
+            self._chk(self.L.ghip_dd_exchange_host(self.h, fn, None))
+        if op == DD_MIGRATE:
+            self.counts()
+
     def dd_run(self, op, params, walk=0):
-        self._chk(self.L.ghip_dd_run(self.h, int(op), C.cast(C.byref(params), C.c_void_p), int(walk)))
+        ptr = None if params is None else C.cast(C.byref(params), C.c_void_p)
+        self._chk(self.L.ghip_dd_run(self.h, int(op), ptr, int(walk)))
+        if op == DD_MIGRATE:
+            self.counts()
 
     def dd_rccl_connect(self, id128):
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
@@ -568,7 +606,8 @@ class ForcePath:
         out = np.zeros(16, np.int64)
         self._chk(self.L.ghip_dd_get_info(self.h, _ptr(out)))
         keys = ("rank", "nranks", "let_imported", "let_sent", "ghosts_imported", "ghosts_sent",
-                "bytes_gravity", "bytes_density", "hsml_growth_e6", "grav_elements", "gas_elements")
+                "bytes_gravity", "bytes_density", "hsml_growth_e6", "grav_elements", "gas_elements",
+                "numpart", "ngas", "migrated_out", "migrated_in", "bytes_migrate")
         return dict(zip(keys, (int(v) for v in out)))
 
     # ---- multi-GPU shard exchange helpers (device pointers, e.g. torch tensors' data_ptr()) ----
@@ -586,7 +625,7 @@ class ForcePath:
 
 
 # ---- multi-GPU module-level helpers ----
-DD_GRAVITY, DD_DENSITY, DD_HYDRO = 2, 3, 4
+DD_MIGRATE, DD_GRAVITY, DD_DENSITY, DD_HYDRO = 1, 2, 3, 4
 
 
 def dd_rccl_unique_id():
@@ -620,6 +659,9 @@ def dd_run_local(paths, op, params, walk=0):
         if any(r != rcs[0] for r in rcs):
             raise RuntimeError("shards out of step: %r" % (rcs,))
         if rcs[0] == 0:
+            if op == DD_MIGRATE:
+                for p in paths:
+                    p.counts()
             return
         dd_exchange_local(paths)
 

@@ -289,7 +289,15 @@ static const FieldInfo kField[GHIP_F_COUNT] = {
   /* GRAVCOST */ {0, 1, 1},   /* NUMNGB */ {1, 1, 0},    /* DENSITY */ {1, 1, 0},
   /* DHSMLFAC */ {1, 1, 0},   /* DIVVEL */ {1, 1, 0},    /* CURLVEL */ {1, 1, 0},
   /* PRESSURE */ {1, 1, 0},   /* HYDROACCEL */ {1, 3, 0}, /* MAXSIGNALVEL */ {1, 1, 0},
-  /* TI_CURRENT */ {0, 1, 1}, /* GRAVPM */ {0, 3, 0}};
+  /* TI_CURRENT */ {0, 1, 1}, /* GRAVPM */ {0, 3, 0}, /* ID */ {0, 1, 1}};
+
+// the same table for the migration of ghip_dd.hip
+void ghip_field_info(int f, int *gas, int *ncomp, int *isint)
+{
+  *gas = kField[f].gas;
+  *ncomp = kField[f].ncomp;
+  *isint = kField[f].isint;
+}
 
 static size_t field_count(const ghip_ctx *ctx, int f)
 {

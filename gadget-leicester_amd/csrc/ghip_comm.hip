@@ -228,6 +228,86 @@ extern "C" int ghip_dd_exchange(ghip_ctx *ctx)
   return GHIP_OK;
 }
 
+// ---- through the host ---------------------------------------------------------------------------
+// The same exchange staged through host memory and the CALLER's all-gather of equal-sized blocks
+// (MPI_Allgather in the reference's world, torch.distributed/gloo in this repo's rehearsals): for a
+// host without RCCL between its ranks, and for running several ranks on ONE GPU, which RCCL
+// refuses.  Slow path by construction (PCIe both ways, every rank sees every send buffer).
+extern "C" int ghip_dd_exchange_host(ghip_ctx *ctx,
+                                     int (*allgather)(void *user, const void *send, size_t bytes,
+                                                      void *recv),
+                                     void *user)
+{
+  if(!ctx || !allgather)
+    return GHIP_EINVAL;
+  DDState &D = ctx->dd;
+  DDXchg &x = D.x;
+  if(x.kind == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  const int P_ = D.nranks, me = D.rank;
+  HIPCHK(hipSetDevice(ctx->device));
+  if(x.kind == 1)
+    {
+      std::vector<char> hs(x.bytes), hr(x.bytes * P_);
+      HIPCHK(hipMemcpyAsync(hs.data(), x.send, x.bytes, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if(allgather(user, hs.data(), x.bytes, hr.data()) != 0)
+        return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd_exchange_host: the caller's all-gather failed");
+      GCHK(ghip_ensure(ctx, *x.recv, x.bytes * P_));
+      HIPCHK(hipMemcpyAsync(x.recv->p, hr.data(), x.bytes * P_, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      D.bytes_sent[D.op] += (long long) x.bytes * (P_ - 1);
+      x.kind = 0;
+      return GHIP_OK;
+    }
+  std::vector<int> row(2 * (size_t) P_), rows(2 * (size_t) P_ * P_);
+  long long mytotal = 0;
+  for(int r = 0; r < P_; r++)
+    {
+      row[r] = x.scount[r];
+      row[P_ + r] = x.soff[r];
+      if(x.soff[r] + x.scount[r] > mytotal)
+        mytotal = x.soff[r] + x.scount[r];
+    }
+  if(allgather(user, row.data(), row.size() * sizeof(int), rows.data()) != 0)
+    return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd_exchange_host: the caller's all-gather failed");
+  long long maxtotal = 1;
+  std::vector<int> cnt((size_t) P_ * P_);
+  for(int src = 0; src < P_; src++)
+    for(int dst = 0; dst < P_; dst++)
+      {
+        const int c = rows[(size_t) src * 2 * P_ + dst], o = rows[(size_t) src * 2 * P_ + P_ + dst];
+        cnt[(size_t) src * P_ + dst] = c;
+        if((long long) o + c > maxtotal)
+          maxtotal = (long long) o + c;
+      }
+  const size_t blk = (size_t) maxtotal * x.bytes;
+  std::vector<char> hs(blk), hr(blk * P_);
+  if(mytotal > 0)
+    HIPCHK(hipMemcpyAsync(hs.data(), x.send, (size_t) mytotal * x.bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if(allgather(user, hs.data(), blk, hr.data()) != 0)
+    return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd_exchange_host: the caller's all-gather failed");
+  recv_layout(x, me, P_, cnt.data());
+  GCHK(ghip_ensure(ctx, *x.recv, (size_t) (x.rtotal > 0 ? x.rtotal : 1) * x.bytes));
+  for(int src = 0; src < P_; src++)
+    {
+      if(x.rcount[src] == 0)
+        continue;
+      const int o = rows[(size_t) src * 2 * P_ + P_ + me];
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(x.recv->p) + (size_t) x.roff[src] * x.bytes,
+                            hr.data() + (size_t) src * blk + (size_t) o * x.bytes,
+                            (size_t) x.rcount[src] * x.bytes, hipMemcpyHostToDevice, st));
+    }
+  HIPCHK(hipStreamSynchronize(st));
+  for(int dst = 0; dst < P_; dst++)
+    if(dst != me)
+      D.bytes_sent[D.op] += (long long) x.scount[dst] * (long long) x.bytes;
+  x.kind = 0;
+  return GHIP_OK;
+}
+
 // ---- shards of one process ------------------------------------------------------------------------
 extern "C" int ghip_dd_exchange_local(ghip_ctx **ctxs, int n)
 {

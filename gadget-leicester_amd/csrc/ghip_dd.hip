@@ -41,6 +41,7 @@ int ghip_dd_refresh_ghosts(ghip_ctx *ctx);
 void ghip_dd_comm_release(ghip_ctx *ctx);
 extern "C" int ghip_dd_exchange(ghip_ctx *ctx);
 
+#define DD_OP_MIGRATE 1
 #define DD_OP_GRAVITY 2
 #define DD_OP_DENSITY 3
 #define DD_OP_HYDRO 4
@@ -1060,9 +1061,296 @@ static int density_step(ghip_ctx *ctx)
   return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: density has no phase %d", D.phase);
 }
 
+// ---- migration --------------------------------------------------------------------------------
+// domain_exchange (domain.c:665-1060): after a drift some particles lie outside their shard's key
+// range; each moves to the shard that owns its key, with every resident field.  One record per
+// particle: 8-byte slots, the fields in enum order (ints widened), slot MIG_SLOTS-1 = 1 for gas.
+#define MIG_SLOTS 40
+struct MigRec
+{
+  unsigned long long s[MIG_SLOTS];
+};
+struct MigField
+{
+  void *p;
+  int ncomp, isint, gas, slot;
+};
+struct MigTable
+{
+  int nf;
+  MigField f[GHIP_F_COUNT];
+};
+struct MigSplits
+{
+  int nranks, me;
+  unsigned long long s[GHIP_MAXRANKS + 1];
+};
+
+void ghip_field_info(int f, int *gas, int *ncomp, int *isint);   // api.hip
+
+static MigTable mig_table(DevBuf *bufs)
+{
+  MigTable T;
+  T.nf = GHIP_F_COUNT;
+  int slot = 0;
+  for(int f = 0; f < GHIP_F_COUNT; f++)
+    {
+      ghip_field_info(f, &T.f[f].gas, &T.f[f].ncomp, &T.f[f].isint);
+      T.f[f].p = bufs[f].p;
+      T.f[f].slot = slot;
+      slot += T.f[f].ncomp;
+    }
+  return T;   // slot <= MIG_SLOTS - 1 (checked by ghip_dd_begin)
+}
+
+__global__ void k_mig_dest(int n, const double *__restrict__ x, const double *__restrict__ y,
+                           const double *__restrict__ z, double cx, double cy, double cz, double fac,
+                           MigSplits S, unsigned long long *__restrict__ mask)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const unsigned long long k =
+    d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac), (int) ((z[i] - cz) * fac));
+  int lo = 0, hi = S.nranks - 1;   // largest r with s[r] <= k
+  while(lo < hi)
+    {
+      int mid = (lo + hi + 1) >> 1;
+      if(S.s[mid] <= k)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+  mask[i] = (lo == S.me) ? 0ULL : (1ULL << lo);
+}
+
+__global__ void k_mig_pack(int nrec, const int *__restrict__ list, int n, int ngas, MigTable T,
+                           MigRec *__restrict__ out)
+{
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if(a >= nrec)
+    return;
+  const int i = list[a];
+  MigRec &r = out[a];
+  const bool isgas = i < ngas;
+  for(int f = 0; f < T.nf; f++)
+    {
+      const MigField F = T.f[f];
+      const size_t pitch = F.gas ? ngas : n;
+      for(int c = 0; c < F.ncomp; c++)
+        {
+          unsigned long long v = 0;
+          if(!F.gas || isgas)
+            {
+              if(F.isint)
+                v = (unsigned long long) (unsigned int) reinterpret_cast<const int *>(F.p)[c * pitch + i];
+              else
+                v = reinterpret_cast<const unsigned long long *>(F.p)[c * pitch + i];
+            }
+          r.s[F.slot + c] = v;
+        }
+    }
+  r.s[MIG_SLOTS - 1] = isgas ? 1ULL : 0ULL;
+}
+
+// keep / gas flags packed for ONE scan: low word counts gas, high word counts the other types
+__global__ void k_mig_flags_old(int n, int ngas, const unsigned long long *__restrict__ mask,
+                                unsigned long long *__restrict__ v)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    v[i] = mask[i] ? 0ULL : (i < ngas ? 1ULL : (1ULL << 32));
+}
+
+__global__ void k_mig_flags_new(int nrecv, const MigRec *__restrict__ rec,
+                                unsigned long long *__restrict__ v)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if(j < nrecv)
+    v[j] = rec[j].s[MIG_SLOTS - 1] ? 1ULL : (1ULL << 32);
+}
+
+struct MigCounts
+{
+  int kg, ko, rg, ro;   // kept gas / other, received gas / other
+};
+
+__global__ void k_mig_move_old(int n, int ngas, const unsigned long long *__restrict__ mask,
+                               const unsigned long long *__restrict__ rank, MigCounts C, MigTable A,
+                               MigTable Bn)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n || mask[i])
+    return;
+  const bool isgas = i < ngas;
+  const int nn = C.kg + C.ko + C.rg + C.ro, ngn = C.kg + C.rg;
+  const unsigned long long rk = rank[i];
+  const int j = isgas ? (int) (rk & 0xffffffffULL) : ngn + (int) (rk >> 32);
+  for(int f = 0; f < A.nf; f++)
+    {
+      const MigField F = A.f[f], G = Bn.f[f];
+      if(F.gas && !isgas)
+        continue;
+      const size_t po = F.gas ? ngas : n, pn = F.gas ? ngn : nn;
+      for(int c = 0; c < F.ncomp; c++)
+        {
+          if(F.isint)
+            reinterpret_cast<int *>(G.p)[c * pn + j] = reinterpret_cast<const int *>(F.p)[c * po + i];
+          else
+            reinterpret_cast<double *>(G.p)[c * pn + j] =
+              reinterpret_cast<const double *>(F.p)[c * po + i];
+        }
+    }
+}
+
+__global__ void k_mig_move_new(int nrecv, const MigRec *__restrict__ rec,
+                               const unsigned long long *__restrict__ rank, MigCounts C, MigTable Bn)
+{
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if(a >= nrecv)
+    return;
+  const MigRec &r = rec[a];
+  const bool isgas = r.s[MIG_SLOTS - 1] != 0;
+  const int nn = C.kg + C.ko + C.rg + C.ro, ngn = C.kg + C.rg;
+  const unsigned long long rk = rank[a];
+  const int j = isgas ? C.kg + (int) (rk & 0xffffffffULL) : ngn + C.ko + (int) (rk >> 32);
+  for(int f = 0; f < Bn.nf; f++)
+    {
+      const MigField G = Bn.f[f];
+      if(G.gas && !isgas)
+        continue;
+      const size_t pn = G.gas ? ngn : nn;
+      for(int c = 0; c < G.ncomp; c++)
+        {
+          const unsigned long long v = r.s[G.slot + c];
+          if(G.isint)
+            reinterpret_cast<int *>(G.p)[c * pn + j] = (int) (unsigned int) v;
+          else
+            reinterpret_cast<unsigned long long *>(G.p)[c * pn + j] = v;
+        }
+    }
+}
+
+static int scan_u64(ghip_ctx *ctx, const unsigned long long *in, unsigned long long *out, int n)
+{
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, n, ctx->stream));
+  GCHK(ghip_ensure(ctx, ctx->cubtmp, tb + 256));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, in, out, n, ctx->stream));
+  return GHIP_OK;
+}
+
+static int migrate_step(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  hipStream_t st = ctx->stream;
+  const int P_ = D.nranks, n = ctx->n, ng = ctx->ngas;
+  if(D.phase == 0)
+    {
+      GHIP_JOIN(ctx);
+      int scount[GHIP_MAXRANKS], soff[GHIP_MAXRANKS], total = 0;
+      for(int r = 0; r < GHIP_MAXRANKS; r++)
+        scount[r] = soff[r] = 0;
+      GCHK(ghip_ensure(ctx, D.mig_mask, (size_t) (n > 0 ? n : 1) * 8));
+      if(n > 0 && P_ > 1)
+        {
+          MigSplits S;
+          S.nranks = P_;
+          S.me = D.rank;
+          for(int r = 0; r <= P_; r++)
+            S.s[r] = D.splits[r];
+          const double *x = P<double>(ctx->f[GHIP_F_POS]);
+          const double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);
+          k_mig_dest<<<cdiv(n, 256), 256, 0, st>>>(n, x, x + n, x + 2 * (size_t) n, ctx->corner[0],
+                                                   ctx->corner[1], ctx->corner[2], fac, S,
+                                                   P<unsigned long long>(D.mig_mask));
+          HIPCHK(hipGetLastError());
+          GCHK(multi_select(ctx, n, P<unsigned long long>(D.mig_mask), D.mig_list, scount, soff, &total));
+        }
+      else if(n > 0)
+        HIPCHK(hipMemsetAsync(D.mig_mask.p, 0, (size_t) n * 8, st));
+      GCHK(ghip_ensure(ctx, D.mig_send, (size_t) (total > 0 ? total : 1) * sizeof(MigRec)));
+      if(total > 0)
+        {
+          k_mig_pack<<<cdiv(total, 256), 256, 0, st>>>(total, P<int>(D.mig_list), n, ng,
+                                                      mig_table(ctx->f), P<MigRec>(D.mig_send));
+          HIPCHK(hipGetLastError());
+        }
+      D.mig_out = total;
+      set_alltoallv(D, D.mig_send.p, sizeof(MigRec), scount, soff, &D.mig_recv);
+      D.phase = 1;
+      return 1;
+    }
+  if(D.phase == 1)
+    {
+      const int nrecv = D.x.rtotal;
+      D.mig_in = nrecv;
+      D.phase = 2;
+      D.op = 0;
+      if(nrecv == 0 && D.mig_out == 0)
+        return GHIP_OK;   // nobody left, nobody came: the resident arrays stay as they are
+      // new positions: kept gas, received gas, kept others, received others
+      GCHK(ghip_ensure(ctx, D.mig_scan, (size_t) (n + nrecv + 2) * 16));
+      unsigned long long *vo = P<unsigned long long>(D.mig_scan), *ro = vo + (n + 1),
+                         *vn = ro + (n + 1), *rn = vn + (nrecv + 1);
+      // (layout: flags_old[n+1], rank_old[n+1], flags_new[nrecv+1], rank_new[nrecv+1]; the extra
+      // zero entry makes the last rank the total)
+      HIPCHK(hipMemsetAsync(vo, 0, (size_t) (n + nrecv + 2) * 16, st));
+      if(n > 0)
+        k_mig_flags_old<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<unsigned long long>(D.mig_mask), vo);
+      if(nrecv > 0)
+        k_mig_flags_new<<<cdiv(nrecv, 256), 256, 0, st>>>(nrecv, P<MigRec>(D.mig_recv), vn);
+      HIPCHK(hipGetLastError());
+      GCHK(scan_u64(ctx, vo, ro, n + 1));
+      GCHK(scan_u64(ctx, vn, rn, nrecv + 1));
+      unsigned long long tot[2];
+      HIPCHK(hipMemcpyAsync(&tot[0], ro + n, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&tot[1], rn + nrecv, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      MigCounts C;
+      C.kg = (int) (tot[0] & 0xffffffffULL);
+      C.ko = (int) (tot[0] >> 32);
+      C.rg = (int) (tot[1] & 0xffffffffULL);
+      C.ro = (int) (tot[1] >> 32);
+      const int nn = C.kg + C.ko + C.rg + C.ro, ngn = C.kg + C.rg;
+      for(int f = 0; f < GHIP_F_COUNT; f++)
+        {
+          int gas, ncomp, isint;
+          ghip_field_info(f, &gas, &ncomp, &isint);
+          size_t bytes = (size_t) (gas ? ngn : nn) * ncomp * (isint ? 4 : 8);
+          size_t before = D.fshadow[f].cap;
+          GCHK(ghip_ensure(ctx, D.fshadow[f], bytes));
+          if(D.fshadow[f].cap != before)
+            HIPCHK(hipMemsetAsync(D.fshadow[f].p, 0, D.fshadow[f].cap, st));
+        }
+      const MigTable A = mig_table(ctx->f), Bn = mig_table(D.fshadow);
+      if(n > 0)
+        k_mig_move_old<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<unsigned long long>(D.mig_mask), ro, C,
+                                                     A, Bn);
+      if(nrecv > 0)
+        k_mig_move_new<<<cdiv(nrecv, 256), 256, 0, st>>>(nrecv, P<MigRec>(D.mig_recv), rn, C, Bn);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));
+      for(int f = 0; f < GHIP_F_COUNT; f++)
+        {
+          DevBuf t = ctx->f[f];
+          ctx->f[f] = D.fshadow[f];
+          D.fshadow[f] = t;
+        }
+      ctx->n = nn;
+      ctx->ngas = ngn;
+      ctx->gt.built = false;
+      ctx->st.built = false;
+      ctx->nactive = -1;
+      ctx->lists_dirty = true;
+      return GHIP_OK;
+    }
+  return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: migration has no phase %d", D.phase);
+}
+
 extern "C" int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk)
 {
-  if(!ctx || !params)
+  if(!ctx || (!params && op != DD_OP_MIGRATE))
     return GHIP_EINVAL;
   DDState &D = ctx->dd;
   if(!D.on)
@@ -1084,6 +1372,19 @@ extern "C" int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk
     D.dp = *reinterpret_cast<const ghip_dens_params *>(params);
   else if(op == DD_OP_HYDRO)
     D.hp = *reinterpret_cast<const ghip_hydro_params *>(params);
+  else if(op == DD_OP_MIGRATE)
+    {
+      static_assert(sizeof(MigRec) == MIG_SLOTS * 8, "MigRec layout");
+      int slots = 0;
+      for(int f = 0; f < GHIP_F_COUNT; f++)
+        {
+          int gas, ncomp, isint;
+          ghip_field_info(f, &gas, &ncomp, &isint);
+          slots += ncomp;
+        }
+      if(slots > MIG_SLOTS - 1)
+        return ghip_fail(ctx, GHIP_EINVAL, "migration record too small for %d field slots", slots);
+    }
   else
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_begin: unknown operation %d", op);
   D.op = op;
@@ -1102,6 +1403,8 @@ extern "C" int ghip_dd_step(ghip_ctx *ctx)
   if(D.x.kind != 0)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: run the pending exchange first");
   HIPCHK(hipSetDevice(ctx->device));
+  if(D.op == DD_OP_MIGRATE)
+    return migrate_step(ctx);
   if(D.op == DD_OP_GRAVITY)
     return gravity_step(ctx);
   if(D.op == DD_OP_DENSITY)
@@ -1146,6 +1449,11 @@ extern "C" int ghip_dd_get_info(const ghip_ctx *ctx, long long out[16])
   out[8] = (long long) (D.gh_growth * 1.0e6);
   out[9] = ctx->gt.nelem;
   out[10] = ctx->st.nelem;
+  out[11] = ctx->n;
+  out[12] = ctx->ngas;
+  out[13] = D.mig_out;
+  out[14] = D.mig_in;
+  out[15] = D.bytes_sent[DD_OP_MIGRATE];
   return GHIP_OK;
 }
 
@@ -1158,12 +1466,20 @@ void ghip_dd_release(ghip_ctx *ctx)
   DevBuf *bs[] = {&D.xstage, &D.grp_own, &D.grp_all, &D.reach, &D.sendm, &D.selcnt, &D.let_list,
                   &D.let_send, &D.let_recv, &D.src_x, &D.src_y, &D.src_z, &D.src_m, &D.src_aux,
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
-                  &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt};
+                  &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,
+                  &D.mig_send, &D.mig_recv, &D.mig_scan};
   for(DevBuf *b : bs)
     {
       if(b->p)
         (void) hipFree(b->p);
       b->p = nullptr;
       b->cap = 0;
+    }
+  for(int f = 0; f < GHIP_F_COUNT; f++)
+    {
+      if(D.fshadow[f].p)
+        (void) hipFree(D.fshadow[f].p);
+      D.fshadow[f].p = nullptr;
+      D.fshadow[f].cap = 0;
     }
 }

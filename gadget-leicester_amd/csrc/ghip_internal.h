@@ -133,6 +133,10 @@ struct DDState
   DevBuf gh_ratio;                // f64[2]: largest Hsml growth seen by the density iterations
   DevBuf gsx, gsy, gsz, gsm, gsh; // gas sources = local gas + ghosts (tree build input)
   DevBuf h0;                      // f64[ngas]: smoothing lengths the ghost selection was made with
+  // migration (domain_exchange): destination masks, send lists, records, shadow field arrays
+  DevBuf mig_mask, mig_list, mig_send, mig_recv, mig_scan;
+  DevBuf fshadow[GHIP_F_COUNT];
+  int mig_out = 0, mig_in = 0;
   // traffic of the last operation (bytes this rank sent over links, excluding its own block)
   long long bytes_sent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };

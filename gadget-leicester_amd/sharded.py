@@ -192,25 +192,41 @@ class DomainShards:
     def hydro(self, params):
         self.run(self.B.DD_HYDRO, params)
 
+    def migrate(self):
+        self.run(self.B.DD_MIGRATE, None)
+
 
 class DomainRank:
-    """One shard per process over RCCL.  `bcast(obj_or_None)` is the host's broadcast from rank 0
-    (MPI_Bcast in the reference's world, torch.distributed.broadcast_object_list in bench.py): it
-    carries the 128-byte RCCL id once."""
+    """One shard per process.  transport "rccl": the exchanges run in C over RCCL; `bcast(obj)` is
+    the host's broadcast from rank 0 (MPI_Bcast in the reference's world,
+    torch.distributed.broadcast_object_list in bench.py) and carries the 128-byte RCCL id once.
+    transport "host": every exchange is staged through host memory and `allgather(bytes) -> bytes`
+    (ghip_dd_exchange_host) -- the rehearsal form for several ranks on one GPU."""
 
-    def __init__(self, path, rank, nranks, bcast):
+    def __init__(self, path, rank, nranks, bcast=None, transport="rccl", allgather=None):
         self.p, self.rank, self.nranks = path, int(rank), int(nranks)
         self.B = _bindings()
+        self.transport, self.allgather = transport, allgather
         path.dd_init(rank, nranks)
-        uid = self.B.dd_rccl_unique_id() if rank == 0 else None
-        uid = bcast(uid)
-        path.dd_rccl_connect(uid)
+        if transport == "rccl":
+            uid = self.B.dd_rccl_unique_id() if rank == 0 else None
+            uid = bcast(uid)
+            path.dd_rccl_connect(uid)
+
+    def _run(self, op, params, walk=0):
+        if self.transport == "rccl":
+            self.p.dd_run(op, params, walk)
+        else:
+            self.p.dd_run_host(op, params, self.allgather, walk)
 
     def gravity(self, params, walk):
-        self.p.dd_run(self.B.DD_GRAVITY, params, walk)
+        self._run(self.B.DD_GRAVITY, params, walk)
 
     def density(self, params):
-        self.p.dd_run(self.B.DD_DENSITY, params)
+        self._run(self.B.DD_DENSITY, params)
 
     def hydro(self, params):
-        self.p.dd_run(self.B.DD_HYDRO, params)
+        self._run(self.B.DD_HYDRO, params)
+
+    def migrate(self):
+        self._run(self.B.DD_MIGRATE, None)

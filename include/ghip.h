@@ -80,6 +80,8 @@ enum ghip_field
   GHIP_F_MAXSIGNALVEL,   /* SphP[].MaxSignalVel [ngas] f64 out */
   GHIP_F_TI_CURRENT,     /* P[].Ti_current    [n]    i32 in/out (ghip_drift) */
   GHIP_F_GRAVPM,         /* P[].GravPM        [n][3] f64 out (ghip_pm_periodic; PMGRID builds) */
+  GHIP_F_ID,             /* P[].ID            [n]    i32 in  (carried along by the multi-GPU
+                          *                                   migration; no kernel reads it) */
   GHIP_F_COUNT
 };
 
@@ -291,6 +293,10 @@ int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_all, int nra
  * where <exchange> is ghip_dd_exchange (this rank's part of a collective over RCCL: ncclAllGather,
  * or ncclAllGather of counts + grouped ncclSend/ncclRecv) or ghip_dd_exchange_local (all shards of
  * one process at once, device-to-device copies).  ghip_dd_run = the whole loop over RCCL. */
+#define GHIP_DD_MIGRATE 1    /* params: NULL.  Particles that drifted out of their shard's key range
+                              * move to the shard that owns them, with every resident field
+                              * (domain_exchange, domain.c:665-1060); numpart / ngas of the
+                              * contexts change, gas stays in front.  Run after ghip_drift. */
 #define GHIP_DD_GRAVITY 2    /* params: ghip_grav_params, walk: GHIP_WALK_*; tree build included */
 #define GHIP_DD_DENSITY 3    /* params: ghip_dens_params; needs the gravity tree of this step */
 #define GHIP_DD_HYDRO 4      /* params: ghip_hydro_params; after GHIP_DD_DENSITY + ghip_update_hmax */
@@ -320,6 +326,12 @@ int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk);
 int ghip_dd_step(ghip_ctx *ctx);                 /* 1: exchange pending, 0: done, < 0: error */
 int ghip_dd_exchange(ghip_ctx *ctx);             /* RCCL */
 int ghip_dd_exchange_local(ghip_ctx **ctxs, int nranks);
+/* the pending exchange staged through host memory and the CALLER's all-gather of equal-sized
+ * blocks (recv = [nranks][bytes]; return 0) -- MPI_Allgather for a host whose ranks have no RCCL
+ * between them; also the only way to rehearse several ranks on ONE GPU.  Slow by construction. */
+int ghip_dd_exchange_host(ghip_ctx *ctx,
+                          int (*allgather)(void *user, const void *send, size_t bytes, void *recv),
+                          void *user);
 int ghip_dd_run(ghip_ctx *ctx, int op, const void *params, int walk);
 /* out[0..10]: rank, nranks, elements imported into the gravity tree, elements sent, ghosts
  * imported, ghosts sent, bytes sent by the last gravity / density operation, largest Hsml growth

@@ -4,7 +4,7 @@
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2..: one PMC group each
 # (counters are collected in their own runs, never together with API tracing), on a shorter run.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

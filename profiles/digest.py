@@ -82,6 +82,30 @@ def main():
                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md",
                "source": "profiles/%s_walk_pmc.json" % tag}
     json.dump(traffic, open(os.path.join(here, "grav_walk_traffic.json"), "w"), indent=1)
+    # VALU wave-instructions per element visit of this binary: SQ_INSTS_VALU per launch of the PMC
+    # pass over the element visits per launch the same run reported (its bench line).  bench.py
+    # multiplies it with its own live visit counter for the issue-slot fraction of the roofline.
+    valu = None
+    for f in sorted(glob.glob(os.path.join(src, "pmc*.log"))):
+        txt = open(f).read()
+        if "SQ_INSTS_VALU" not in open(f.replace(".log", "/p_counter_collection.csv")).read(200000) \
+                if os.path.exists(f.replace(".log", "/p_counter_collection.csv")) else True:
+            continue
+        for line in txt.splitlines():
+            if line.startswith('{"metric"'):
+                rec = json.loads(line)
+                steps = rec["work_per_step_rank0"]["grav_wave_steps"]
+                valu = {"ng": 64, "kernel": "k_grav_walk<NEWTON>",
+                        "SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"]["mean"],
+                        "element_visits_per_launch": steps,
+                        "valu_insts_per_wave_step": c["SQ_INSTS_VALU"]["mean"] / steps,
+                        "hbm_bytes_per_launch": traffic["hbm_bytes_per_launch"],
+                        "source": "profiles/%s_walk_pmc.json + the bench line of the same PMC pass" % tag,
+                        "note": "SQ_INSTS_VALU counts wave-instructions; a full-rate 64-bit VALU "
+                                "instruction holds its SIMD for 4 cycles"}
+    if valu:
+        json.dump(valu, open(os.path.join(here, "%s_walk_valu.json" % tag), "w"), indent=1)
+        print(json.dumps(valu, indent=1))
     print(json.dumps(derived, indent=1))
 
 

@@ -185,6 +185,7 @@ class ShardSet:
                 fp.set_field(B.F_TIMEBIN, pr.timebin[g])
                 fp.set_field(B.F_TI_BEGSTEP, pr.ti_begstep[g])
                 fp.set_field(B.F_OLDACC, extra.get("oldacc", np.zeros(pr.n))[g])
+                fp.set_field(B.F_ID, g.astype(np.int32))      # global index, follows the particle
             if ngl:
                 gg = g[:ngl]
                 fp.set_field(B.F_VELPRED, pr.velpred[gg])
@@ -214,6 +215,15 @@ class ShardSet:
             if len(g):
                 out[g] = fp.get_field(field)
         return out
+
+    def migrate(self):
+        """GHIP_DD_MIGRATE on all shards, then re-read who holds what from the ID field"""
+        self.run.run(self.B.DD_MIGRATE, None)
+        for r, fp in enumerate(self.fp):
+            n, ngl = fp.counts()
+            self.gid[r] = fp.get_field(self.B.F_ID).astype(np.int64) if n else np.zeros(0, np.int64)
+            self.ngas[r] = ngl
+            self.owner[self.gid[r]] = r
 
     def each(self, fn):
         return [fn(fp) for fp in self.fp]

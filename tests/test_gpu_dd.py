@@ -147,3 +147,89 @@ def test_config_c4_128cubed_as_eight_logical_shards():
         assert all(0 < i["let_imported"] < 0.6 * n for i in info)
     finally:
         S.close()
+
+
+def test_migration_moves_every_field_with_its_particle():
+    """GHIP_DD_MIGRATE (domain_exchange, domain.c:665-1060): after the particles have moved, every
+    one lies in the key range of the shard that holds it, every resident field has followed its
+    particle, gas stays in front -- and the forces of the re-sharded set equal the single tree's."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    S = ShardSet(pr, 4)
+    try:
+        rng = np.random.default_rng(21)
+        tag = {B.F_VEL: pr.ic["vel"], B.F_MASS: pr.ic["mass"], B.F_OLDACC: rng.random(n),
+               B.F_GRAVACCEL: rng.standard_normal((n, 3)), B.F_GRAVCOST: rng.integers(1, 900, n).astype(np.int32),
+               B.F_TI_BEGSTEP: rng.integers(0, 64, n).astype(np.int32), B.F_TIMEBIN: pr.timebin,
+               B.F_HSML: pr.hsml0, B.F_VELPRED: pr.velpred, B.F_ENTROPY: pr.entropy,
+               B.F_DENSITY: 1 + rng.random(ng), B.F_HYDROACCEL: rng.standard_normal((ng, 3)),
+               B.F_MAXSIGNALVEL: rng.random(ng)}
+        for fid, arr in tag.items():
+            S.set_field(fid, arr)
+        # a sizeable shake: a quarter of the particles change shard
+        newpos = np.mod(pr.ic["pos"] + 0.08 * rng.standard_normal((n, 3)), 1.0)
+        newpos[newpos >= 1.0] = 0.0
+        S.set_field(B.F_POS, newpos)
+        before = S.owner.copy()
+        S.migrate()
+        moved = int((S.owner != before).sum())
+        info = S.each(lambda fp: fp.dd_info())
+        assert moved > n // 10 and moved == sum(i["migrated_out"] for i in info)
+        assert sum(i["migrated_out"] for i in info) == sum(i["migrated_in"] for i in info)
+        allid = np.sort(np.concatenate(S.gid))
+        assert np.array_equal(allid, np.arange(n))                       # nobody lost, nobody doubled
+        for r, fp in enumerate(S.fp):
+            k = fp.dd_keys()
+            assert np.all((k >= S.splits[r]) & (k < S.splits[r + 1]))
+            t = fp.get_field(B.F_TYPE)
+            assert np.all(t[:S.ngas[r]] == 0) and np.all(t[S.ngas[r]:] != 0)
+            assert np.all(S.gid[r][:S.ngas[r]] < ng) and np.all(S.gid[r][S.ngas[r]:] >= ng)
+        assert np.array_equal(S.get_field(B.F_POS), newpos)
+        for fid, arr in tag.items():
+            assert np.array_equal(S.get_field(fid), arr), fid
+        # and the path runs on the re-sharded set
+        pr2 = Problem(ng=10, gas=True, periodic=1)
+        pr2.ic["pos"] = newpos
+        pr2.extent = pr.extent
+        T = pr2.oracle_tree()
+        tg = np.arange(n, dtype=np.int32)
+        S.set_field(B.F_OLDACC, np.zeros(n))
+        oacc, ocost = T.gravity(pr2.o_grav(pr.theta), tg, np.zeros(n))
+        S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
+        assert np.array_equal(S.get_field(B.F_GRAVCOST), ocost)
+        assert relerr(S.get_field(B.F_GRAVACCEL), oacc) < TOL
+    finally:
+        S.close()
+
+
+def test_rccl_path_single_rank():
+    """The RCCL entry points on the one GPU of this box: a communicator of one rank (RCCL refuses
+    two ranks on one device), the whole gravity + SPH sequence through ghip_dd_run -- i.e.
+    ncclCommInitRank, ncclAllGather and the (empty) grouped send/receive are really called -- against
+    the oracle."""
+    B = bindings()
+    pr = Problem(ng=8, gas=True, periodic=1)
+    fp = pr.device()
+    fp.dd_init(0, 1)
+    fp.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+    fp.dd_set_splits(np.array([0, 1 << 63], np.uint64))
+    assert B.dd_rccl_library().endswith(("librccl.so.1", "librccl.so"))
+    fp.dd_rccl_connect(B.dd_rccl_unique_id())
+    fp.set_field(B.F_OLDACC, np.zeros(pr.n))
+    fp.dd_run(B.DD_MIGRATE, None)
+    fp.dd_run(B.DD_GRAVITY, pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
+    fp.dd_run(B.DD_DENSITY, pr.g_dens())
+    fp.update_hmax()
+    fp.dd_run(B.DD_HYDRO, pr.g_hydro())
+    T = pr.oracle_tree()
+    tg = np.arange(pr.n, dtype=np.int32)
+    oacc, ocost = T.gravity(pr.o_grav(pr.theta), tg, np.zeros(pr.n))
+    T.gravity_ewald_add(pr.o_grav(pr.theta), O.ewald_table(pr.box), tg, np.zeros(pr.n), oacc, ocost)
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), ocost)
+    assert relerr(fp.get_field(B.F_GRAVACCEL), oacc) < TOL
+    act = np.arange(pr.ngas, dtype=np.int32)
+    od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                   pr.ti_begstep, pr.hsml0)
+    assert relerr(fp.get_field(B.F_DENSITY), od["density"][:pr.ngas]) < TOL
+    fp.close()
