@@ -188,9 +188,71 @@ void gadget_force_layout(ghip_layout *lay)
   lay->p_ti_current = (int) offsetof(struct particle_data, Ti_current);
 }
 
+/* ---- `All` of a host with the reference's full struct: members by byte offset ---------------- */
+static char *HostAll = NULL;
+static struct gadget_force_all_layout HostAllLay;
+
+struct all_member
+{
+  size_t own_off, size;
+  int writeback;
+};
+#define GF_MEMBER(m) { offsetof(struct global_data_all_processes, m), sizeof(All.m), 0 },
+static struct all_member AllMembers[] = { GADGET_FORCE_ALL_MEMBERS(GF_MEMBER) };
+#undef GF_MEMBER
+#define N_ALL_MEMBERS ((int) (sizeof(AllMembers) / sizeof(AllMembers[0])))
+
+int gadget_force_all_layout_count(void)
+{
+  return N_ALL_MEMBERS;
+}
+
+static void all_mark_writeback(size_t own_off)
+{
+  for(int k = 0; k < N_ALL_MEMBERS; k++)
+    if(AllMembers[k].own_off == own_off)
+      AllMembers[k].writeback = 1;
+}
+
+void gadget_force_bind_all(void *host_All, const struct gadget_force_all_layout *offsets)
+{
+  HostAll = (host_All && offsets) ? (char *) host_All : NULL;
+  if(HostAll)
+    HostAllLay = *offsets;
+  /* what the path itself changes (gravtree.c:396-397, 783, 835-884) */
+  all_mark_writeback(offsetof(struct global_data_all_processes, ErrTolTheta));
+  all_mark_writeback(offsetof(struct global_data_all_processes, TotNumOfForces));
+  all_mark_writeback(offsetof(struct global_data_all_processes, SofteningTable));
+  all_mark_writeback(offsetof(struct global_data_all_processes, ForceSoftening));
+  all_mark_writeback(offsetof(struct global_data_all_processes, MinGasHsml));
+}
+
+/* host -> library: at the top of every entry point */
+static void all_pull(void)
+{
+  if(!HostAll)
+    return;
+  const int *off = (const int *) &HostAllLay;
+  for(int k = 0; k < N_ALL_MEMBERS; k++)
+    if(off[k] >= 0)
+      memcpy((char *) &All + AllMembers[k].own_off, HostAll + off[k], AllMembers[k].size);
+}
+
+/* library -> host: after the path changed one of its members */
+static void all_push(void)
+{
+  if(!HostAll)
+    return;
+  const int *off = (const int *) &HostAllLay;
+  for(int k = 0; k < N_ALL_MEMBERS; k++)
+    if(off[k] >= 0 && AllMembers[k].writeback)
+      memcpy(HostAll + off[k], (char *) &All + AllMembers[k].own_off, AllMembers[k].size);
+}
+
 /* gravtree.c:835-884 */
 void set_softenings(void)
 {
+  all_pull();
   const double soft[6] = { All.SofteningGas, All.SofteningHalo, All.SofteningDisk,
     All.SofteningBulge, All.SofteningStars, All.SofteningBndry };
   const double maxphys[6] = { All.SofteningGasMaxPhys, All.SofteningHaloMaxPhys,
@@ -206,6 +268,7 @@ void set_softenings(void)
   for(int i = 0; i < 6; i++)
     All.ForceSoftening[i] = 2.8 * All.SofteningTable[i];
   All.MinGasHsml = All.MinGasHsmlFractional * All.ForceSoftening[0];
+  all_push();
 }
 
 /* gravtree.c:892-907 */
@@ -262,6 +325,7 @@ void mysort_dataindex(void *b, size_t n, size_t s, int (*cmp)(const void *, cons
 /* darkenergy.c:389-409 without DARKENERGY */
 double hubble_function(double a)
 {
+  all_pull();
   double hubble_a = All.Omega0 / (a * a * a) + (1 - All.Omega0 - All.OmegaLambda) / (a * a) +
     All.OmegaLambda;
   return All.Hubble * sqrt(hubble_a);
@@ -339,6 +403,7 @@ peanokey peano_hilbert_key(int x, int y, int z, int bits)
 /* ------------------------------------------------------------------------------------------ */
 static int need_ctx(const char *who)
 {
+  all_pull();   /* every driver starts here: the host's `All` is the state (gadget_force_bind_all) */
   if(Ctx)
     return 0;
   snprintf(ErrBuf, sizeof(ErrBuf), "%s: gadget_force_init() has not succeeded (no GPU context)",
@@ -557,7 +622,10 @@ void gravity_tree(void)
   if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
     return;
   if(All.TypeOfOpeningCriterion == 1)
-    All.ErrTolTheta = 0; /* gravtree.c:396-397 */
+    {
+      All.ErrTolTheta = 0; /* gravtree.c:396-397 */
+      all_push();
+    }
   /* gravtree.c:470-483: vacuum energy in physical coordinates */
   if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn == 0)
     if(chk(ghip_gravity_vacuum_energy(Ctx, All.OmegaLambda * All.Hubble * All.Hubble),
@@ -568,6 +636,7 @@ void gravity_tree(void)
   if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))
     return;
   All.TotNumOfForces += nact;
+  all_push();
   Phase = 1;
   CPU_Step_Treewalk += wallclock() - t0;
 }

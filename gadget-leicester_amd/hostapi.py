@@ -69,7 +69,26 @@ class Config(C.Structure):
 
 ENDRUN_CB = C.CFUNCTYPE(None, C.c_int)
 
-EXPORTS = ["gadget_force_init", "gadget_force_finalize", "gadget_force_last_error",
+# GADGET_FORCE_ALL_MEMBERS of include/gadget_force.h: (name, numpy type) in table order
+ALL_MEMBERS = [
+    ("MaxPart", "i4"), ("G", "f8"), ("ErrTolTheta", "f8"), ("ErrTolForceAcc", "f8"),
+    ("TypeOfOpeningCriterion", "i4"), ("BoxSize", "f8"), ("DesNumNgb", "f8"),
+    ("MaxNumNgbDeviation", "f8"), ("MinGasHsmlFractional", "f8"), ("MinGasHsml", "f8"),
+    ("ArtBulkViscConst", "f8"), ("Ti_Current", "i4"), ("Timebase_interval", "f8"), ("Time", "f8"),
+    ("ComovingIntegrationOn", "i4"), ("Hubble", "f8"), ("Omega0", "f8"), ("OmegaLambda", "f8"),
+    ("SofteningGas", "f8"), ("SofteningHalo", "f8"), ("SofteningDisk", "f8"),
+    ("SofteningBulge", "f8"), ("SofteningStars", "f8"), ("SofteningBndry", "f8"),
+    ("SofteningGasMaxPhys", "f8"), ("SofteningHaloMaxPhys", "f8"), ("SofteningDiskMaxPhys", "f8"),
+    ("SofteningBulgeMaxPhys", "f8"), ("SofteningStarsMaxPhys", "f8"),
+    ("SofteningBndryMaxPhys", "f8"), ("SofteningTable", ("f8", 6)), ("ForceSoftening", ("f8", 6)),
+    ("Rcut", ("f8", 2)), ("Asmth", ("f8", 2)), ("TotNumOfForces", "i8"), ("BunchSize", "i4"),
+    ("BufferSize", "f8"), ("ErrTolIntAccuracy", "f8"), ("CourantFac", "f8"),
+    ("MaxSizeTimestep", "f8"), ("MinSizeTimestep", "f8"), ("MaxRMSDisplacementFac", "f8"),
+    ("OmegaBaryon", "f8"), ("MinEgySpec", "f8"), ("TypeOfTimestepCriterion", "i4"),
+    ("StarformationOn", "i4")]
+
+EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
+           "gadget_force_init", "gadget_force_finalize", "gadget_force_last_error",
            "gadget_force_ctx", "gadget_force_layout", "gadget_force_set_endrun",
            "gadget_force_mark_dirty", "endrun", "set_softenings", "data_index_compare",
            "mysort_dataindex", "domain_findExtent",
@@ -103,6 +122,8 @@ def lib():
         _pkg.lib_path()  # libghip.so must exist too
         L = C.CDLL(lib_path(), mode=C.RTLD_GLOBAL)
         L.gadget_force_init.argtypes = [C.POINTER(Config)]
+        L.gadget_force_bind_all.argtypes = [C.c_void_p, C.c_void_p]
+        L.gadget_force_bind_all.restype = None
         L.gadget_force_last_error.restype = C.c_char_p
         L.gadget_force_ctx.restype = C.c_void_p
         L.gadget_force_set_endrun.argtypes = [ENDRUN_CB]
@@ -141,7 +162,20 @@ class Host:
                                (rc, self.L.gadget_force_last_error().decode()))
         self.All = AllStruct.in_dll(self.L, "All")
 
+    def bind_all(self, host_all, offsets):
+        """gadget_force_bind_all: `host_all` a numpy structured scalar/array holding the host's own
+        struct, `offsets` {member: byte offset} (missing members: -1).  None unbinds."""
+        if host_all is None:
+            self.L.gadget_force_bind_all(None, None)
+            self._bound = None
+            return
+        assert self.L.gadget_force_all_layout_count() == len(ALL_MEMBERS)
+        tab = (C.c_int * len(ALL_MEMBERS))(*[int(offsets.get(name, -1)) for name, _ in ALL_MEMBERS])
+        self._bound = (host_all, tab)            # keep both alive
+        self.L.gadget_force_bind_all(C.c_void_p(host_all.ctypes.data), tab)
+
     def close(self):
+        self.L.gadget_force_bind_all(None, None)
         self.L.gadget_force_finalize()
 
     def _setp(self, name, arr):

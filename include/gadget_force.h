@@ -150,6 +150,36 @@ struct global_data_all_processes
   int TypeOfTimestepCriterion, StarformationOn;
 };
 
+/* A host whose `All` is the reference's full struct (allvars.h:530-1123, ~300 members whose
+ * layout depends on the -D flags) cannot share the subset above.  Like P[]/SphP[] (ghip_layout) it
+ * hands over BYTE OFFSETS instead: gadget_force_bind_all(&All_of_the_host, &offsets) makes every
+ * entry point of this library read the members below from the host's struct and write back the ones
+ * the path changes (ErrTolTheta gravtree.c:396-397, TotNumOfForces :783, SofteningTable /
+ * ForceSoftening / MinGasHsml :835-884).  One int per member, in the order of GADGET_FORCE_ALL_MEMBERS;
+ * -1 = the host's build has no such member (the library keeps its own value, 0 unless set).
+ * A probe TU fills the table with offsetof(struct global_data_all_processes, member), INTEGRATION.md. */
+#define GADGET_FORCE_ALL_MEMBERS(X)                                                               \
+  X(MaxPart) X(G) X(ErrTolTheta) X(ErrTolForceAcc) X(TypeOfOpeningCriterion) X(BoxSize)          \
+  X(DesNumNgb) X(MaxNumNgbDeviation) X(MinGasHsmlFractional) X(MinGasHsml) X(ArtBulkViscConst)   \
+  X(Ti_Current) X(Timebase_interval) X(Time) X(ComovingIntegrationOn) X(Hubble) X(Omega0)        \
+  X(OmegaLambda) X(SofteningGas) X(SofteningHalo) X(SofteningDisk) X(SofteningBulge)              \
+  X(SofteningStars) X(SofteningBndry) X(SofteningGasMaxPhys) X(SofteningHaloMaxPhys)             \
+  X(SofteningDiskMaxPhys) X(SofteningBulgeMaxPhys) X(SofteningStarsMaxPhys)                       \
+  X(SofteningBndryMaxPhys) X(SofteningTable) X(ForceSoftening) X(Rcut) X(Asmth)                   \
+  X(TotNumOfForces) X(BunchSize) X(BufferSize) X(ErrTolIntAccuracy) X(CourantFac)                 \
+  X(MaxSizeTimestep) X(MinSizeTimestep) X(MaxRMSDisplacementFac) X(OmegaBaryon) X(MinEgySpec)     \
+  X(TypeOfTimestepCriterion) X(StarformationOn)
+struct gadget_force_all_layout
+{
+#define GADGET_FORCE_X(m) int m;
+  GADGET_FORCE_ALL_MEMBERS(GADGET_FORCE_X)
+#undef GADGET_FORCE_X
+};
+/* host_All == NULL unbinds (the library's own `All` is the state again).  The member types must be
+ * the reference's (int / double / long long, MyFloat == double: DOUBLEPRECISION builds). */
+void gadget_force_bind_all(void *host_All, const struct gadget_force_all_layout *offsets);
+int gadget_force_all_layout_count(void);   /* number of ints in the table (ABI check for bindings) */
+
 /* allvars.h:1673-1684: export bookkeeping record other translation units sort with the two
  * functions below (blackhole.c:366, dust.c:114, density.c:186 ...) */
 struct data_index

@@ -57,17 +57,22 @@ def main():
             d["wait_inst_fraction_of_wave_cycles"] = (c["SQ_WAIT_INST_ANY"]["mean"] /
                                                       c["SQ_WAVE_CYCLES"]["mean"])
         if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
-            # 256 CUs x 4 SIMDs, one VALU instruction issued per SIMD per cycle at best
-            d["valu_issue_fraction_of_peak"] = (c["SQ_INSTS_VALU"]["mean"] /
-                                                (c["GRBM_GUI_ACTIVE"]["mean"] * 1024))
+            # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS
+            # note): cycles of the launch = GRBM / 8.  256 CUs x 4 SIMDs; a 64-bit VALU
+            # wave-instruction holds its SIMD for 4 cycles.
+            cyc = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+            d["valu_insts_per_simd_cycle"] = c["SQ_INSTS_VALU"]["mean"] / (cyc * 1024)
+            d["valu_issue_slot_fraction"] = 4.0 * c["SQ_INSTS_VALU"]["mean"] / (cyc * 1024)
         if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-            d["mean_resident_waves_per_simd"] = (c["SQ_WAVE_CYCLES"]["mean"] /
-                                                 (c["GRBM_GUI_ACTIVE"]["mean"] * 1024))
+            # SQ_WAVE_CYCLES counts quad-cycles
+            d["mean_resident_waves_per_simd"] = (4.0 * c["SQ_WAVE_CYCLES"]["mean"] /
+                                                 (c["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024))
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             d["l2_hit_rate"] = c["TCC_HIT_sum"]["mean"] / (c["TCC_HIT_sum"]["mean"] +
                                                           c["TCC_MISS_sum"]["mean"])
         if "GRBM_GUI_ACTIVE" in c:
-            d["mean_clock_GHz"] = c["GRBM_GUI_ACTIVE"]["mean"] / c["GRBM_GUI_ACTIVE"]["mean_duration_ns"]
+            d["mean_clock_GHz"] = (c["GRBM_GUI_ACTIVE"]["mean"] / 8.0 /
+                                   c["GRBM_GUI_ACTIVE"]["mean_duration_ns"])
         derived[label] = d
     out = {"note": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 3 "
                    "--warmup 1 --no-cpu-baseline (profiles/collect.sh); relative-criterion launches "
@@ -87,11 +92,10 @@ def main():
     # multiplies it with its own live visit counter for the issue-slot fraction of the roofline.
     valu = None
     for f in sorted(glob.glob(os.path.join(src, "pmc*.log"))):
-        txt = open(f).read()
-        if "SQ_INSTS_VALU" not in open(f.replace(".log", "/p_counter_collection.csv")).read(200000) \
-                if os.path.exists(f.replace(".log", "/p_counter_collection.csv")) else True:
+        csvf = os.path.join(f[:-4], "p_counter_collection.csv")
+        if not os.path.exists(csvf) or "SQ_INSTS_VALU" not in open(csvf).read(400000):
             continue
-        for line in txt.splitlines():
+        for line in open(f).read().splitlines():
             if line.startswith('{"metric"'):
                 rec = json.loads(line)
                 steps = rec["work_per_step_rank0"]["grav_wave_steps"]

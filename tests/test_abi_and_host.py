@@ -231,3 +231,55 @@ def test_walk_touch_registers_stay_reserved_inside_the_loop():
                 assert not any(lo <= r <= hi for r in regs), ins
         checked += 1
     assert checked >= 4      # the Newtonian and short-range walks, periodic or not
+
+
+def test_all_of_a_host_with_another_struct_layout_is_read_and_written_through_offsets():
+    """gadget_force_bind_all: a host whose struct global_data_all_processes is laid out differently
+    (here: the members in reverse order, separated by padding, next to members this library has never
+    heard of) hands over byte offsets.  set_softenings() (gravtree.c:835-884) and hubble_function()
+    (darkenergy.c:389) are pure host arithmetic, so this runs without a GPU: they must read the
+    host's struct and set_softenings must write SofteningTable / ForceSoftening / MinGasHsml back
+    into it."""
+    import ctypes as C
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    L = H.lib()
+    assert L.gadget_force_all_layout_count() == len(H.ALL_MEMBERS)
+    names, formats, offsets, off = [], [], [], 40                 # 40 bytes of foreign members first
+    for name, fmt in reversed(H.ALL_MEMBERS):
+        names.append(name)
+        formats.append(fmt)
+        offsets.append(off)
+        off += np.dtype(fmt).itemsize + 24                        # and 24 bytes between any two
+    dt = np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": off + 64})
+    A = np.zeros(1, dt)
+    A["SofteningGas"], A["SofteningHalo"], A["SofteningDisk"] = 0.01, 0.02, 0.03
+    A["SofteningBulge"], A["SofteningStars"], A["SofteningBndry"] = 0.04, 0.05, 0.06
+    for k in ("Gas", "Halo", "Disk", "Bulge", "Stars", "Bndry"):
+        A["Softening%sMaxPhys" % k] = 0.004
+    A["ComovingIntegrationOn"], A["Time"], A["MinGasHsmlFractional"] = 1, 0.25, 0.5
+    A["Hubble"], A["Omega0"], A["OmegaLambda"] = 0.1, 0.3, 0.7
+    raw = A.view(np.uint8).copy()
+    tab = (C.c_int * len(H.ALL_MEMBERS))(*[dt.fields[n][1] for n, _ in H.ALL_MEMBERS])
+    try:
+        L.gadget_force_bind_all(C.c_void_p(A.ctypes.data), tab)
+        L.set_softenings()
+        # comoving: soft * a > maxphys for all but the gas (0.01 * 0.25 = 0.0025 < 0.004)
+        want = np.array([0.01, 0.016, 0.016, 0.016, 0.016, 0.016])
+        assert np.allclose(A["SofteningTable"][0], want, rtol=0, atol=1e-18)
+        assert np.array_equal(A["ForceSoftening"][0], 2.8 * A["SofteningTable"][0])
+        assert A["MinGasHsml"][0] == 0.5 * A["ForceSoftening"][0][0]
+        a = 0.25
+        hub = 0.1 * np.sqrt(0.3 / a ** 3 + 0.7)
+        assert abs(L.hubble_function(a) - hub) < 1e-15
+        A["Hubble"] = 0.2                                         # the host's struct IS the state
+        assert abs(L.hubble_function(a) - 2 * hub) < 1e-15
+        # nothing but the three members the path owns was written
+        now = A.view(np.uint8)
+        changed = np.nonzero(now != raw)[1] if now.ndim == 2 else np.nonzero(now != raw)[0]
+        ok = np.zeros(dt.itemsize, bool)
+        for n in ("SofteningTable", "ForceSoftening", "MinGasHsml", "Hubble"):
+            o = dt.fields[n][1]
+            ok[o:o + dt.fields[n][0].itemsize] = True
+        assert ok[changed].all()
+    finally:
+        L.gadget_force_bind_all(None, None)

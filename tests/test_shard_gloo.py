@@ -1,4 +1,9 @@
-"""world_size-2 test of the multi-GPU step driver on CPU (gloo).
+"""world_size-2 tests of the multi-GPU host logic on CPU (gloo).
+
+(1) the replicated-source driver (ShardedForceStep), (2) the domain decomposition's partition rule
+(sharded.decompose + the library's ghip_dd_find_split = domain_findSplit_work_balanced) with a real
+two-process exchange.
+
 
 gadget-leicester_amd/sharded.py orchestrates: replicated tree, sharded targets, one all-gather
 per phase.  Here the engine is a CPU stand-in with the device engine's interface (compute by the
@@ -51,10 +56,17 @@ class OracleEngine:
         self.order = np.argsort(keys, kind="stable").astype(np.int32)        # tree order
         self.order_gas = self.order[self.order < pr.ngas]
 
-    def _slice(self, gas):
+    def _slice(self, gas, rank=None):
+        """the device's rule (ghip_shard_range / k_shard_permute, ghip_internal.h, ghip_tree.hip):
+        the ordered target list is cut into buckets of 64, rank r owns buckets r, r+N, r+2N, ...;
+        `per` is the padded common slice length of the all-gathers"""
         lst = self.order_gas if gas else self.order
-        per = (len(lst) + self.world - 1) // self.world
-        return per, lst[self.rank * per:(self.rank + 1) * per], lst
+        rank = self.rank if rank is None else rank
+        nb = (len(lst) + 63) // 64
+        mine = np.concatenate([lst[b * 64:(b + 1) * 64] for b in range(rank, nb, self.world)]
+                              or [lst[:0]])
+        per = ((nb + self.world - 1) // self.world) * 64
+        return per, mine, lst
 
     def shard_count(self, gas):
         per, mine, _ = self._slice(gas)
@@ -117,7 +129,7 @@ class OracleEngine:
         for r in range(nranks):
             if r == self.rank:
                 continue
-            idx = lst[r * per:(r + 1) * per]
+            idx = self._slice(group != 0, rank=r)[1]
             for c, col in enumerate(cols):
                 col[idx] = buf[r, c, :len(idx)].astype(col.dtype)
 
@@ -186,3 +198,94 @@ def test_slices_partition_the_target_list(world):
         seen.append(mine)
     allm = np.concatenate(seen)
     assert len(allm) == pr.n and len(set(allm.tolist())) == pr.n
+
+
+# ------------------------------------------------------------------------------------------------
+# domain decomposition: the partition rule of the multi-GPU path, two real processes
+# ------------------------------------------------------------------------------------------------
+def _dd_inputs(pr):
+    """Peano-Hilbert keys (oracle's table-driven curve) and the reference's work weights
+    (1 + GravCost) / 2^TimeBin (domain.c:378-384) of the whole seeded problem"""
+    fac = (1 << 21) / pr.extent[2]
+    ip = ((pr.ic["pos"] - pr.extent[0]) * fac).astype(np.int64)
+    keys = np.array([O.peano_hilbert_key(x, y, z) for x, y, z in ip], dtype=np.uint64)
+    rng = np.random.default_rng(77)
+    cost = rng.integers(200, 4000, pr.n).astype(np.float64)
+    work = (1.0 + cost) / (1 << pr.timebin)
+    return keys, work
+
+
+def _worker_dd(rank, world, port, ret):
+    import importlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = importlib.import_module("gadget-leicester_amd.sharded")
+    B = importlib.import_module("gadget-leicester_amd.bindings")
+    pr = Problem(ng=8, gas=True, periodic=1)
+    keys_all, work_all = _dd_inputs(pr)
+    mine = np.arange(rank, pr.n, world)                  # any initial distribution
+    keys, work = keys_all[mine], work_all[mine]
+    # what every rank does: local work histogram on the curve, summed over ranks, cut by the
+    # library's domain_findSplit_work_balanced
+    level = S.histogram_level(pr.n)
+    shift = np.uint64(63 - 3 * level)
+    hist = np.bincount((keys >> shift).astype(np.int64), weights=work, minlength=8 ** level)
+    t = torch.from_numpy(hist)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    start, end = B.dd_find_split(world, t.numpy())
+    splits = np.array([int(s) << int(shift) for s in start] + [1 << 63], dtype=np.uint64)
+    splits[0] = 0
+    # migration: everybody tells everybody what it sends where (domain_exchange, domain.c:665)
+    dest = np.searchsorted(splits[1:world], keys, side="right")
+    out = [[int(i) for i in mine[dest == r]] for r in range(world)]
+    box = [None] * world
+    dist.all_gather_object(box, out)
+    have = np.array(sorted(i for src in box for i in src[rank]), dtype=np.int64)
+    ret[rank] = dict(splits=splits, have=have, hist=t.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_domain_decomposition_cuts_and_migrates_like_the_library():
+    import importlib
+    import torch.multiprocessing as mp
+    S = importlib.import_module("gadget-leicester_amd.sharded")
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_dd, args=(world, _free_port(), ret), nprocs=world, join=True)
+    pr = Problem(ng=8, gas=True, periodic=1)
+    keys, work = _dd_inputs(pr)
+    splits, owner = S.decompose(keys, world, work)        # the single-process form of the same rule
+    assert np.array_equal(ret[0]["splits"], splits) and np.array_equal(ret[1]["splits"], splits)
+    allhave = np.concatenate([ret[r]["have"] for r in range(world)])
+    assert np.array_equal(np.sort(allhave), np.arange(pr.n))           # nobody lost or doubled
+    for r in range(world):
+        k = keys[ret[r]["have"]]
+        assert np.all((k >= splits[r]) & (k < splits[r + 1]))          # everybody in its range
+        assert np.array_equal(ret[r]["have"], np.where(owner == r)[0])
+    # balanced to within one cell of the histogram (the greedy cut of domain.c:1075-1113)
+    w = np.array([work[owner == r].sum() for r in range(world)])
+    assert np.abs(w - w.mean()).max() <= ret[0]["hist"].max() + 1e-9
+
+
+@pytest.mark.parametrize("ncpu", [1, 2, 3, 8])
+def test_find_split_is_contiguous_covers_everything_and_follows_the_running_average(ncpu):
+    import importlib
+    B = importlib.import_module("gadget-leicester_amd.bindings")
+    rng = np.random.default_rng(ncpu)
+    w = rng.random(64) * (rng.random(64) < 0.7)           # some empty cells, as on a real curve
+    start, end = B.dd_find_split(ncpu, w)
+    assert start[0] == 0 and end[-1] == len(w) - 1
+    assert np.array_equal(start[1:], end[:-1] + 1)
+    # the reference's rule: a range stops as soon as the running sum reaches the running average
+    avg = w.sum() / ncpu
+    before = 0.0
+    for i in range(ncpu - 1):
+        got = w[start[i]:end[i] + 1].sum()
+        assert before + got >= (i + 1) * avg - 1e-12 or (len(w) - 1 - end[i]) == (ncpu - 1 - i)
+        assert before + got - w[end[i]] < (i + 1) * avg or start[i] == end[i]
+        before += got
