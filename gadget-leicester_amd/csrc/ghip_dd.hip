@@ -416,21 +416,6 @@ __device__ __forceinline__ bool d_group_can_open(const DDGroup &G, const double4
   return false;
 }
 
-__device__ __forceinline__ bool d_rank_can_open(const DDGroup *__restrict__ tab, const double4 &xm,
-                                                const double4 &cl, double aux, const LetK &K)
-{
-  for(int s = 0; s < DD_NSUPER; s++)
-    {
-      if(!d_group_can_open(tab[s], xm, cl, aux, K))
-        continue;
-      const DDGroup *g = tab + DD_NSUPER + s * DD_NSUB;
-      for(int q = 0; q < DD_NSUB; q++)
-        if(d_group_can_open(g[q], xm, cl, aux, K))
-          return true;
-    }
-  return false;
-}
-
 __global__ void k_let_init(int nelem, unsigned long long allmask, unsigned long long *__restrict__ reach,
                            unsigned long long *__restrict__ sendm)
 {
@@ -441,63 +426,112 @@ __global__ void k_let_init(int nelem, unsigned long long allmask, unsigned long 
   sendm[e] = 0ULL;
 }
 
-// one level of the top-down pass: a node some rank reaches is either left as it is for that rank
-// (pruned: sent as one element) or descended (its children become reachable)
-__global__ void k_let_level(int nelem, int level, const int4 *__restrict__ lk,
-                            const double4 *__restrict__ xm, const double4 *__restrict__ cl,
-                            const double *__restrict__ aux,
-                            const unsigned long long *__restrict__ skey,
-                            const DDGroup *__restrict__ groups, LetK K,
-                            unsigned long long *__restrict__ reach,
-                            unsigned long long *__restrict__ sendm)
+__device__ __forceinline__ double d_bcast(double v, int j)
 {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
-    return;
-  const int4 me = lk[e];
-  if(me.y != -(level + 1))
-    return;
-  const unsigned long long r = reach[e];
-  if(r == 0)
+  return __shfl(v, j, 64);
+}
+
+// One level of the top-down pass: a node some rank reaches is either left as it is for that rank
+// (pruned: sent as one element) or descended (its children become reachable).
+// One wavefront per 64 consecutive elements.  Lane-parallel: which of them are nodes of this level
+// that somebody reaches, and does the cell lie wholly inside this shard's key range.  Then, rank by
+// rank: lane l holds super-group l of that rank's table in registers, and the candidates that rank
+// reaches are tested one after the other against all 64 super-groups at once (and against the 16
+// groups of up to four hit super-groups at a time).  Finally every candidate lane publishes its own
+// result and marks its children.
+__global__ void __launch_bounds__(64)
+k_let_level(int nelem, int level, const int4 *__restrict__ lk, const double4 *__restrict__ xm,
+            const double4 *__restrict__ cl, const double *__restrict__ aux,
+            const unsigned long long *__restrict__ skey, const DDGroup *__restrict__ groups, LetK K,
+            unsigned long long *__restrict__ reach, unsigned long long *__restrict__ sendm)
+{
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * 64 + lane;
+  bool cand = false;
+  int4 me = make_int4(0, 0, 0, 0);
+  unsigned long long r = 0;
+  if(e < nelem)
+    {
+      me = lk[e];
+      if(me.y == -(level + 1))
+        {
+          r = reach[e];
+          cand = r != 0;
+        }
+    }
+  if(__ballot(cand) == 0)
     return;
   // does the cell lie wholly inside this shard's key range?  (every octree cell is one contiguous
   // piece of the Peano-Hilbert curve)  If not, other shards hold particles of it too: its local
   // moments are partial and it must be descended for everybody.
   bool shared = true;
-  if(level > 0)
+  double4 m4 = make_double4(0, 0, 0, 0), c4 = make_double4(0, 0, 0, 0);
+  double a = 0;
+  if(cand)
     {
-      const int sh = 3 * (GHIP_BITS - level);
-      const unsigned long long ph = d_peano_of_morton(skey[me.z]);
-      const unsigned long long lo = (ph >> sh) << sh;
-      const unsigned long long hi = lo + (1ULL << sh);
-      shared = !(lo >= K.klo && hi <= K.khi);
-    }
-  unsigned long long X = 0;
-  if(shared)
-    X = r;
-  else
-    {
-      const double4 m4 = xm[e], c4 = cl[e];
-      const double a = aux[e];
-      unsigned long long todo = r;
-      while(todo)
+      if(level > 0)
         {
-          const int b = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          if(d_rank_can_open(groups + (size_t) b * DD_TABLE, m4, c4, a, K))
+          const int sh = 3 * (GHIP_BITS - level);
+          const unsigned long long ph = d_peano_of_morton(skey[me.z]);
+          const unsigned long long lo = (ph >> sh) << sh;
+          const unsigned long long hi = lo + (1ULL << sh);
+          shared = !(lo >= K.klo && hi <= K.khi);
+        }
+      m4 = xm[e];
+      c4 = cl[e];
+      a = aux[e];
+    }
+  unsigned long long X = (cand && shared) ? r : 0ULL;
+  const bool test = cand && !shared;
+  for(int b = 0; b < K.nranks; b++)
+    {
+      unsigned long long cm = __ballot(test && ((r >> b) & 1ULL));
+      if(cm == 0)
+        continue;
+      const DDGroup *tab = groups + (size_t) b * DD_TABLE;
+      const DDGroup Gs = tab[lane];
+      while(cm)
+        {
+          const int j = __builtin_ctzll(cm);
+          cm &= cm - 1;
+          const double4 mj = make_double4(d_bcast(m4.x, j), d_bcast(m4.y, j), d_bcast(m4.z, j),
+                                          d_bcast(m4.w, j));
+          const double4 cj = make_double4(d_bcast(c4.x, j), d_bcast(c4.y, j), d_bcast(c4.z, j),
+                                          d_bcast(c4.w, j));
+          const double aj = d_bcast(a, j);
+          unsigned long long sm = __ballot(d_group_can_open(Gs, mj, cj, aj, K));
+          bool open = false;
+          while(sm && !open)
+            {
+              int sg = -1;
+              for(int q = 0; q < 4 && sm; q++)
+                {
+                  const int s0 = __builtin_ctzll(sm);
+                  sm &= sm - 1;
+                  if((lane >> 4) == q)
+                    sg = s0;
+                }
+              const bool hit = sg >= 0 && d_group_can_open(tab[DD_NSUPER + sg * DD_NSUB + (lane & 15)],
+                                                           mj, cj, aj, K);
+              open = __ballot(hit) != 0;
+            }
+          if(open && lane == j)
             X |= 1ULL << b;
         }
     }
-  sendm[e] = r & ~X;
-  if(X)
-    for(int c = e + 1; c < me.x;)
-      {
-        const int4 ck = lk[c];
-        reach[c] = X;
-        if(ck.y >= 0)
-          sendm[c] = X;   // a particle that is reached is sent
-        c = ck.x;
-      }
+  if(cand)
+    {
+      sendm[e] = r & ~X;
+      if(X)
+        for(int c = e + 1; c < me.x;)
+          {
+            const int4 ck = lk[c];
+            reach[c] = X;
+            if(ck.y >= 0)
+              sendm[c] = X;   // a particle that is reached is sent
+            c = ck.x;
+          }
+    }
 }
 
 __global__ void k_let_single(int nelem, const int4 *__restrict__ lk,
@@ -714,39 +748,121 @@ __device__ __forceinline__ bool d_group_needs(const DDGroup &G, double x, double
   return d0 * d0 + d1 * d1 + d2 * d2 < R * R;
 }
 
-__global__ void k_ghost_select(int ngas, const double *__restrict__ x, const double *__restrict__ y,
-                               const double *__restrict__ z, const double *__restrict__ h,
-                               const DDGroup *__restrict__ groups, GhostK K,
-                               unsigned long long *__restrict__ mask, double *__restrict__ h0)
+// distance test between a chunk of particles (box c +- e, largest padded radius hmax) and a group's box
+__device__ __forceinline__ bool d_group_near_box(const DDGroup &G, double cx, double cy, double cz,
+                                                 double ex, double ey, double ez, double hmax,
+                                                 const GhostK &K)
 {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= ngas)
-    return;
-  const double px = x[i], py = y[i], pz = z[i], hj = h[i] * K.margin;
-  h0[i] = h[i];
-  unsigned long long m = 0;
-  for(int b = 0; b < K.nranks; b++)
+  if(G.ex < 0)
+    return false;
+  double d0 = cx - G.cx, d1 = cy - G.cy, d2 = cz - G.cz;
+  if(K.periodic)
     {
-      if(b == K.me)
-        continue;
-      const DDGroup *tab = groups + (size_t) b * DD_TABLE;
-      bool need = false;
-      for(int s = 0; s < DD_NSUPER && !need; s++)
-        {
-          if(!d_group_needs(tab[s], px, py, pz, hj, K))
-            continue;
-          const DDGroup *g = tab + DD_NSUPER + s * DD_NSUB;
-          for(int q = 0; q < DD_NSUB; q++)
-            if(d_group_needs(g[q], px, py, pz, hj, K))
-              {
-                need = true;
-                break;
-              }
-        }
-      if(need)
-        m |= 1ULL << b;
+      d0 = d_nearest(d0, K.boxsize, K.boxhalf);
+      d1 = d_nearest(d1, K.boxsize, K.boxhalf);
+      d2 = d_nearest(d2, K.boxsize, K.boxhalf);
     }
-  mask[i] = m;
+  d0 = fabs(d0) - G.ex - ex;
+  d1 = fabs(d1) - G.ey - ey;
+  d2 = fabs(d2) - G.ez - ez;
+  d0 = d0 > 0 ? d0 : 0;
+  d1 = d1 > 0 ? d1 : 0;
+  d2 = d2 > 0 ? d2 : 0;
+  const double R = (G.rmax > hmax ? G.rmax : hmax) * (1.0 + 1.0e-9);
+  return d0 * d0 + d1 * d1 + d2 * d2 < R * R;
+}
+
+// One wavefront per (chunk of 64 local gas particles that are neighbours in the gravity tree's
+// (Morton) order, destination rank) -- `src` lists the particles as indices of that tree.  The chunk's
+// bounding box is tested against the 64 super-groups of the rank by the 64 lanes at once; only for
+// the super-groups it comes near are the 16 groups staged through LDS and every lane tests its own
+// particle against the near ones.  Interior chunks -- nearly all of them -- cost one box test.
+// mask[] must be zero on entry; the ranks' bits are OR-ed in.
+__global__ void __launch_bounds__(64)
+k_ghost_select(int nsrc, const int *__restrict__ src, const int *__restrict__ perm,
+               const double *__restrict__ sx, const double *__restrict__ sy,
+               const double *__restrict__ sz, const double *__restrict__ h,
+               const DDGroup *__restrict__ groups, GhostK K, unsigned long long *__restrict__ mask,
+               double *__restrict__ h0)
+{
+  __shared__ DDGroup sh[DD_NSUB];
+  const int lane = threadIdx.x;
+  const int nd = K.nranks - 1;                   // destinations per chunk
+  const int chunk = blockIdx.x / nd;
+  int b = blockIdx.x - chunk * nd;
+  if(b >= K.me)
+    b++;                                         // skip this rank itself
+  const int a = chunk * 64 + lane;
+  const bool valid = a < nsrc;
+  int i = 0;
+  double px = 0, py = 0, pz = 0, hj = 0;
+  if(valid)
+    {
+      const int s = src[a];
+      i = perm[s];
+      px = sx[s];
+      py = sy[s];
+      pz = sz[s];
+      hj = h[i] * K.margin;
+      if(blockIdx.x == chunk * nd)
+        h0[i] = h[i];
+    }
+  // chunk box around lane 0's particle (nearest-image offsets: a chunk is compact, the box may
+  // straddle the periodic boundary)
+  const double rx = __shfl(px, 0, 64), ry = __shfl(py, 0, 64), rz = __shfl(pz, 0, 64);
+  double ox = valid ? px - rx : 0, oy = valid ? py - ry : 0, oz = valid ? pz - rz : 0;
+  if(K.periodic)
+    {
+      ox = d_nearest(ox, K.boxsize, K.boxhalf);
+      oy = d_nearest(oy, K.boxsize, K.boxhalf);
+      oz = d_nearest(oz, K.boxsize, K.boxhalf);
+    }
+  double lo[3] = {ox, oy, oz}, hi[3] = {ox, oy, oz}, hm = hj;
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      for(int k = 0; k < 3; k++)
+        {
+          double o = __shfl_xor(lo[k], off, 64);
+          lo[k] = o < lo[k] ? o : lo[k];
+          o = __shfl_xor(hi[k], off, 64);
+          hi[k] = o > hi[k] ? o : hi[k];
+        }
+      const double o = __shfl_xor(hm, off, 64);
+      hm = o > hm ? o : hm;
+    }
+  const double cx = rx + 0.5 * (lo[0] + hi[0]), cy = ry + 0.5 * (lo[1] + hi[1]),
+               cz = rz + 0.5 * (lo[2] + hi[2]);
+  const double ex = 0.5 * (hi[0] - lo[0]) * (1 + 1e-12) + 1e-14, ey = 0.5 * (hi[1] - lo[1]) * (1 + 1e-12) + 1e-14,
+               ez = 0.5 * (hi[2] - lo[2]) * (1 + 1e-12) + 1e-14;
+  const DDGroup *tab = groups + (size_t) b * DD_TABLE;
+  unsigned long long sm = __ballot(d_group_near_box(tab[lane], cx, cy, cz, ex, ey, ez, hm, K));
+  bool need = false;
+  while(sm)
+    {
+      const int sg = __builtin_ctzll(sm);
+      sm &= sm - 1;
+      __syncthreads();
+      bool near = false;
+      if(lane < DD_NSUB)
+        {
+          const DDGroup G = tab[DD_NSUPER + sg * DD_NSUB + lane];
+          sh[lane] = G;
+          near = d_group_near_box(G, cx, cy, cz, ex, ey, ez, hm, K);
+        }
+      unsigned long long qm = __ballot(near);
+      __syncthreads();
+      while(qm)
+        {
+          const int q = __builtin_ctzll(qm);
+          qm &= qm - 1;
+          if(valid && !need && d_group_needs(sh[q], px, py, pz, hj, K))
+            need = true;
+        }
+      if(__ballot(valid && !need) == 0)
+        break;   // every particle of the chunk is a ghost there already
+    }
+  if(need)
+    atomicOr(mask + i, 1ULL << b);
 }
 
 // GhostRec of local gas particle i (host order): the two records of the SPH kernels
@@ -904,7 +1020,7 @@ static int gravity_step(ghip_ctx *ctx)
                              *sendm = P<unsigned long long>(D.sendm);
           k_let_init<<<cdiv(t.nelem, 256), 256, 0, st>>>(t.nelem, all, reach, sendm);
           for(int L = 0; L <= t.maxlevel; L++)
-            k_let_level<<<cdiv(t.nelem, 256), 256, 0, st>>>(
+            k_let_level<<<cdiv(t.nelem, 64), 64, 0, st>>>(
               t.nelem, L, P<int4>(t.lk), P<double4>(t.xm), P<double4>(t.cl), P<double>(t.aux),
               P<unsigned long long>(t.skey), P<DDGroup>(D.grp_all), K, reach, sendm);
           k_let_single<<<1, 64, 0, st>>>(t.nelem, P<int4>(t.lk), reach, sendm);
@@ -945,6 +1061,14 @@ __global__ void k_flag_gas_targets(int nt, const int *__restrict__ tgt, const in
   int a = blockIdx.x * blockDim.x + threadIdx.x;
   if(a < nt)
     flags[a] = perm[tgt[a]] < ngas ? 1 : 0;
+}
+
+__global__ void k_mask_local_gas(int n, int ngas, const int *__restrict__ perm,
+                                 unsigned long long *__restrict__ mask)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < n)
+    mask[s] = perm[s] < ngas ? 1ULL : 0ULL;
 }
 
 static int density_step(ghip_ctx *ctx)
@@ -1000,12 +1124,21 @@ static int density_step(ghip_ctx *ctx)
           K.margin = D.gh_margin;
           K.nranks = P_;
           K.me = D.rank;
-          const double *x = P<double>(ctx->f[GHIP_F_POS]);
-          k_ghost_select<<<cdiv(ng, 256), 256, 0, st>>>(ng, x, x + n, x + 2 * (size_t) n,
-                                                       P<double>(ctx->f[GHIP_F_HSML]),
-                                                       P<DDGroup>(D.grp_all), K,
-                                                       P<unsigned long long>(D.gh_mask),
-                                                       P<double>(D.h0));
+          // the local gas particles in the gravity tree's order (chunks of 64 are compact)
+          const int nsrc = ctx->gt.n;
+          GCHK(ghip_ensure(ctx, D.sendm, (size_t) nsrc * 8));
+          k_mask_local_gas<<<cdiv(nsrc, 256), 256, 0, st>>>(nsrc, ng, P<int>(ctx->gt.perm),
+                                                           P<unsigned long long>(D.sendm));
+          int c0[GHIP_MAXRANKS], o0[GHIP_MAXRANKS], nfound = 0;
+          GCHK(multi_select(ctx, nsrc, P<unsigned long long>(D.sendm), D.gas_src, c0, o0, &nfound));
+          if(nfound != ng)
+            return ghip_fail(ctx, GHIP_EINVAL, "ghost selection: %d of %d gas particles in the tree",
+                             nfound, ng);
+          HIPCHK(hipMemsetAsync(D.gh_mask.p, 0, (size_t) ng * 8, st));
+          k_ghost_select<<<cdiv(ng, 64) * (P_ - 1), 64, 0, st>>>(
+            ng, P<int>(D.gas_src), P<int>(ctx->gt.perm), P<double>(ctx->sx), P<double>(ctx->sy),
+            P<double>(ctx->sz), P<double>(ctx->f[GHIP_F_HSML]), P<DDGroup>(D.grp_all), K,
+            P<unsigned long long>(D.gh_mask), P<double>(D.h0));
           HIPCHK(hipGetLastError());
           GCHK(multi_select(ctx, ng, P<unsigned long long>(D.gh_mask), D.gh_list, D.gh_scount,
                             D.gh_soff, &total));
@@ -1467,7 +1600,7 @@ void ghip_dd_release(ghip_ctx *ctx)
                   &D.let_send, &D.let_recv, &D.src_x, &D.src_y, &D.src_z, &D.src_m, &D.src_aux,
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
                   &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,
-                  &D.mig_send, &D.mig_recv, &D.mig_scan};
+                  &D.mig_send, &D.mig_recv, &D.mig_scan, &D.gas_src};
   for(DevBuf *b : bs)
     {
       if(b->p)

@@ -55,8 +55,8 @@ struct TreeDev
 // targets along the space-filling curve.  A group is (bounding box, the least OldAcc of its
 // targets, the largest search radius); other shards test their tree nodes / gas particles against
 // these boxes to decide what this shard can possibly need (ghip_dd.hip).
-#define DD_NSUPER 32
-#define DD_NSUB 32
+#define DD_NSUPER 64   // = lanes of a wavefront: one test of a node against all super-groups of a rank
+#define DD_NSUB 16
 #define DD_NGROUPS (DD_NSUPER * DD_NSUB)
 #define DD_TABLE (DD_NSUPER + DD_NGROUPS)   // records per shard: super-groups first
 struct __attribute__((aligned(64))) DDGroup
@@ -121,6 +121,7 @@ struct DDState
   int let_sent = 0, gh_sent = 0;
   double gh_growth = 0;
   DevBuf gas_tgt;                 // i32: the local gas targets in curve order (gravity-tree indices)
+  DevBuf gas_src;                 // i32: all local gas particles in gravity-tree order
   int gt_nimp = 0;                // imported elements the next gravity-tree build includes
   DevBuf src_x, src_y, src_z, src_m, src_aux, src_key, src_lvl;   // sources = local particles + imports
   // SPH: ghost gas particles
