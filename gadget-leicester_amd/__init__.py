@@ -19,7 +19,7 @@ LIBHOST = os.path.join(PKG_DIR, "libgadget_force.so")
 
 HIP_SOURCES = ["ghip_api.hip", "ghip_tree.hip", "ghip_gravity.hip", "ghip_sph.hip",
                "ghip_shard.hip", "ghip_drift.hip", "ghip_kick.hip", "ghip_export.hip", "ghip_pm.hip",
-               "ghip_dd.hip", "ghip_comm.hip"]
+               "ghip_dd.hip", "ghip_comm.hip", "ghip_sink.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 

@@ -91,6 +91,16 @@ class PmKickParams(C.Structure):
                 ("dt_gravkickB", C.c_double)]
 
 
+class BhParams(C.Structure):
+    """ghip_bh_params: the sink passes of the shipped flag bundle (include/ghip.h, row N4)"""
+    _fields_ = [("BoxSize", C.c_double), ("periodic", C.c_int), ("ascale", C.c_double),
+                ("dt_fac", C.c_double), ("SMBHmass", C.c_double), ("InnerBoundary", C.c_double),
+                ("SinkBoundary", C.c_double), ("SofteningBndry", C.c_double),
+                ("CritDensity", C.c_double), ("FeedbackCoeff", C.c_double),
+                ("UnitMass_in_g", C.c_double), ("dust", C.c_int),
+                ("accretion_of_dust_only", C.c_int), ("accretion_density", C.c_int)]
+
+
 class PmParams(C.Structure):
     _fields_ = [("pmgrid", C.c_int), ("BoxSize", C.c_double), ("G", C.c_double),
                 ("Asmth", C.c_double)]
@@ -162,7 +172,9 @@ EXPORTS = [
     "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
     "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
-    "ghip_dd_exchange_local", "ghip_dd_exchange_host", "ghip_dd_run", "ghip_dd_get_info"]
+    "ghip_dd_exchange_local", "ghip_dd_exchange_host", "ghip_dd_run", "ghip_dd_get_info",
+    "ghip_sink_density", "ghip_sink_reset", "ghip_blackhole_evaluate", "ghip_blackhole_swallow",
+    "ghip_sink_get_marks", "ghip_sink_set_marks", "ghip_cooling_and_starformation"]
 
 
 def lib():
@@ -238,6 +250,16 @@ def lib():
         L.ghip_dd_run.argtypes = [vp, C.c_int, vp, C.c_int]
         L.ghip_dd_exchange_host.argtypes = [vp, ALLGATHER_CB, vp]
         L.ghip_dd_get_info.argtypes = [vp, vp]
+        L.ghip_sink_density.argtypes = [vp, C.POINTER(DensParams), C.c_double, C.c_int, vp, vp, vp,
+                                        vp, vp, vp, C.POINTER(C.c_int)]
+        L.ghip_sink_reset.argtypes = [vp]
+        L.ghip_blackhole_evaluate.argtypes = [vp, C.POINTER(BhParams), C.c_int, vp, vp, vp, vp]
+        L.ghip_blackhole_swallow.argtypes = [vp, C.POINTER(BhParams), C.c_int, vp, vp, vp, vp, vp,
+                                             vp, vp, vp]
+        L.ghip_sink_get_marks.argtypes = [vp, vp, vp]
+        L.ghip_sink_set_marks.argtypes = [vp, vp, vp]
+        L.ghip_cooling_and_starformation.argtypes = [vp, C.c_double, C.c_double, C.c_double,
+                                                     C.c_double, vp]
         _LIB = L
     return _LIB
 
@@ -525,6 +547,62 @@ class ForcePath:
     @property
     def stream(self):
         return self.L.ghip_stream(self.h)
+
+    # ---- "next" row N4: sinks ----
+    def sink_density(self, params, ngb_factor, sinks, hsml):
+        sinks = np.ascontiguousarray(sinks, np.int32)
+        ns = len(sinks)
+        out = dict(hsml=np.ascontiguousarray(hsml, np.float64).copy(), numngb=np.zeros(ns),
+                   density=np.zeros(ns), entropy=np.zeros(ns), gasvel=np.zeros((ns, 3)))
+        it = C.c_int(0)
+        self._chk(self.L.ghip_sink_density(self.h, C.byref(params), float(ngb_factor), ns, _ptr(sinks),
+                                           _ptr(out["hsml"]), _ptr(out["numngb"]),
+                                           _ptr(out["density"]), _ptr(out["entropy"]),
+                                           _ptr(out["gasvel"]), C.byref(it)))
+        out["iterations"] = it.value
+        return out
+
+    def sink_reset(self):
+        self._chk(self.L.ghip_sink_reset(self.h))
+
+    def blackhole_evaluate(self, params, sinks, sink_ids, mdot, bh_density):
+        sinks = np.ascontiguousarray(sinks, np.int32)
+        ids = np.ascontiguousarray(sink_ids, np.uint32)
+        md = np.ascontiguousarray(mdot, np.float64)
+        rho = np.ascontiguousarray(bh_density, np.float64)
+        self._chk(self.L.ghip_blackhole_evaluate(self.h, C.byref(params), len(sinks), _ptr(sinks),
+                                                 _ptr(ids), _ptr(md), _ptr(rho)))
+
+    def blackhole_swallow(self, params, sinks, sink_ids, sink_bh_mass):
+        sinks = np.ascontiguousarray(sinks, np.int32)
+        ids = np.ascontiguousarray(sink_ids, np.uint32)
+        ns = len(sinks)
+        out = dict(bh_mass=np.ascontiguousarray(sink_bh_mass, np.float64).copy(),
+                   acc_mass=np.zeros(ns), acc_bhmass=np.zeros(ns), acc_dustmass=np.zeros(ns),
+                   acc_momentum=np.zeros((ns, 3)), counts=np.zeros(3, np.int64))
+        self._chk(self.L.ghip_blackhole_swallow(self.h, C.byref(params), ns, _ptr(sinks), _ptr(ids),
+                                                _ptr(out["bh_mass"]), _ptr(out["acc_mass"]),
+                                                _ptr(out["acc_bhmass"]), _ptr(out["acc_dustmass"]),
+                                                _ptr(out["acc_momentum"]), _ptr(out["counts"])))
+        return out
+
+    def sink_marks(self):
+        sw = np.zeros(self.n, np.uint32)
+        inj = np.zeros(self.ngas)
+        self._chk(self.L.ghip_sink_get_marks(self.h, _ptr(sw), _ptr(inj)))
+        return sw, inj
+
+    def set_sink_marks(self, swallow_id=None, injected=None):
+        sw = None if swallow_id is None else np.ascontiguousarray(swallow_id, np.uint32)
+        inj = None if injected is None else np.ascontiguousarray(injected, np.float64)
+        self._chk(self.L.ghip_sink_set_marks(self.h, _ptr(sw), _ptr(inj)))
+
+    def cooling_and_starformation(self, timebase, crit_density, min_egy, u_to_temp_fac):
+        flag = np.zeros(self.ngas, np.int32)
+        self._chk(self.L.ghip_cooling_and_starformation(self.h, float(timebase), float(crit_density),
+                                                        float(min_egy), float(u_to_temp_fac),
+                                                        _ptr(flag)))
+        return flag
 
     # ---- multi-GPU: domain decomposition with tree-node / ghost exchange (include/ghip.h) ----
     def dd_init(self, rank, nranks):

@@ -218,6 +218,8 @@ struct ghip_ctx
   ghip_stats stats;
   hipEvent_t ev[16];
   DDState dd;                // multi-GPU domain decomposition (ghip_dd.hip)
+  DevBuf bh_swallow, bh_injected;   // "next" row N4 (ghip_sink.hip): P[].SwallowID u32[n],
+                                    // SphP[].i.Injected_BH_Energy f64[ngas]
   int timestep_endrun = 0;   // endrun code of the last ghip_advance_timesteps failure
   bool ev_ready = false;
 };

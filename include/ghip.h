@@ -374,6 +374,64 @@ int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int MaxPart, in
  * field is zeroed first as long_range_force does).  Pairs with GHIP_WALK_SHORTRANGE. ---- */
 int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p);
 
+/* ---- "next" row N4: sink (black-hole) neighbour passes and the per-particle part of
+ * cooling_and_starformation, for the reference's shipped flag bundle (BLACK_HOLES, SWALLOWGAS,
+ * ACCRETION_RADIUS, ACCRETION_DENSITY, ACCRETION_OF_DUST_ONLY, BH_MERGERS_WITHIN_H,
+ * BH_THERMALFEEDBACK + TMP_FEEDBACK, DUST, COOLING, SFR, BH_FORM).  The sinks are given by their
+ * particle indices; their per-sink state (ID, Mdot, BH_Density, BH_Mass ...) travels in small host
+ * arrays, the victims' marks (P[].SwallowID, SphP[].i.Injected_BH_Energy) are resident.  Scalar
+ * bookkeeping per sink (blackhole_accretion(), blackhole.c:133-300, 680-760), the conversion of a
+ * flagged gas particle into a sink (sfr_eff.c:606-640, GSL stream) and DoCooling (cooling.c) stay
+ * host code.  Single-GPU contexts only. ---- */
+typedef struct
+{
+  double BoxSize;
+  int periodic;
+  double ascale;            /* All.Time when comoving, else 1 (blackhole.c:89-95) */
+  double dt_fac;            /* All.Timebase_interval / hubble_a (:822) */
+  double SMBHmass, InnerBoundary, SinkBoundary, SofteningBndry;   /* All.* */
+  double CritDensity;       /* All.CritOverDensity * UnitLength_in_cm^3 / UnitMass_in_g (:1099) */
+  double FeedbackCoeff;     /* All.BlackHoleFeedbackFactor * 6.67e-8 * pow(4.*3.1415/3.*5., 0.3333)
+                               / All.UnitEnergy_in_cgs (:1138-1139) */
+  double UnitMass_in_g;
+  int dust;                   /* -DDUST */
+  int accretion_of_dust_only; /* -DACCRETION_OF_DUST_ONLY */
+  int accretion_density;      /* -DACCRETION_DENSITY */
+} ghip_bh_params;
+/* density() for Type-5 targets (density.c BLACK_HOLES branches): h iteration against the gas tree
+ * for DesNumNgb * ngb_factor (All.BlackHoleNgbFactor) neighbours.  hsml [nsink] in/out (also
+ * written to the resident HSML field); numngb, bh_density, bh_entropy [nsink], bh_gasvel
+ * [nsink][3].  Needs the tree of this step. */
+int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, double ngb_factor, int nsink,
+                      const int *sink_idx, double *hsml, double *numngb, double *bh_density,
+                      double *bh_entropy, double *bh_gasvel, int *iterations);
+/* P[].SwallowID = 0, Injected_BH_Energy = 0 for all particles (start of blackhole_accretion) */
+int ghip_sink_reset(ghip_ctx *ctx);
+/* blackhole_evaluate (blackhole.c:794-1190): marks the victims (SwallowID = ID of the sink; a
+ * victim claimed by several sinks goes to the largest ID) and spreads the feedback energy.
+ * Reads POS, VEL, MASS, HSML, TIMEBIN, TYPE and the gas DENSITY from the resident fields. */
+int ghip_blackhole_evaluate(ghip_ctx *ctx, const ghip_bh_params *p, int nsink, const int *sink_idx,
+                            const unsigned int *sink_id, const double *bh_mdot,
+                            const double *bh_density);
+/* blackhole_evaluate_swallow (blackhole.c:1201-1346): per sink the accreted mass, BH mass, dust
+ * mass [nsink] and momentum [nsink][3]; the victims' resident MASS becomes 0 (a tree built before
+ * is stale afterwards), sink_bh_mass [nsink] (P[].BH_Mass of the sinks, in/out) becomes 0 for a
+ * swallowed sink; counts = gas / sinks / dust swallowed. */
+int ghip_blackhole_swallow(ghip_ctx *ctx, const ghip_bh_params *p, int nsink, const int *sink_idx,
+                           const unsigned int *sink_id, double *sink_bh_mass, double *acc_mass,
+                           double *acc_bhmass, double *acc_dustmass, double *acc_momentum,
+                           long long counts[3]);
+/* the resident marks: SwallowID [numpart] (u32), Injected_BH_Energy [ngas]; NULL = skip */
+int ghip_sink_get_marks(ghip_ctx *ctx, unsigned int *swallow_id, double *injected_energy);
+int ghip_sink_set_marks(ghip_ctx *ctx, const unsigned int *swallow_id, const double *injected_energy);
+/* cooling_and_starformation (sfr_eff.c:82-947), per active gas particle (ghip_set_active), with the
+ * cooling function as identity: flag_sink_host [ngas] = 1 where the particle qualifies for
+ * conversion into a sink (:226-229), else the isochoric update of DTENTROPY incl. the injected
+ * black-hole energy (:486-531, 582-594).  Non-comoving. */
+int ghip_cooling_and_starformation(ghip_ctx *ctx, double Timebase_interval,
+                                   double CritPhysDensity_code, double MinEgySpec,
+                                   double u_to_temp_fac, int *flag_sink_host);
+
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
                     double DomainLen, const double ForceSoftening[6]);

@@ -2055,3 +2055,428 @@ void orc_pm_kick(int n, int ngas, int ti_current, double timebase, const double 
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row N4: sink (black-hole) neighbour passes of the shipped flag bundle
+ * (BLACK_HOLES, SWALLOWGAS, ACCRETION_RADIUS, ACCRETION_DENSITY, ACCRETION_OF_DUST_ONLY,
+ *  BH_MERGERS_WITHIN_H, BH_THERMALFEEDBACK + TMP_FEEDBACK, DUST; Makefile:67-72, 96, 124, 199-204)
+ * ---------------------------------------------------------------------------------------- */
+
+/* ngb_treefind_blackhole (blackhole.c:1351-1474), mode 0: like ngb_treefind_variable, but gas,
+ * sinks and (DUST) dust grains are candidates */
+static int ngb_treefind_blackhole(const orc_tree *t, const double c[3], double hsml, int dust,
+                                  int periodic, double boxsize, int *ngblist)
+{
+  double boxhalf = 0.5 * boxsize;
+  int numngb = 0;
+  int no = t->n;
+  while(no >= 0)
+    {
+      if(no < t->n)
+        {
+          int p = no;
+          no = t->nextnode[no];
+          int ty = t->type[p];
+          if(ty != 0 && ty != 5 && !(dust && ty == 2)) /* :1372-1380 */
+            continue;
+          double dist = hsml;
+          double dx = ngb_periodic(t->pos[3 * p + 0] - c[0], periodic, boxsize, boxhalf);
+          if(dx > dist)
+            continue;
+          double dy = ngb_periodic(t->pos[3 * p + 1] - c[1], periodic, boxsize, boxhalf);
+          if(dy > dist)
+            continue;
+          double dz = ngb_periodic(t->pos[3 * p + 2] - c[2], periodic, boxsize, boxhalf);
+          if(dz > dist)
+            continue;
+          if(dx * dx + dy * dy + dz * dz > dist * dist)
+            continue;
+          ngblist[numngb++] = p;
+        }
+      else
+        {
+          const onode *cur = &NODE(t, no);
+          double dist = hsml + 0.5 * cur->len; /* :1453 */
+          no = cur->sibling;
+          double dx = ngb_periodic(cur->center[0] - c[0], periodic, boxsize, boxhalf);
+          if(dx > dist)
+            continue;
+          double dy = ngb_periodic(cur->center[1] - c[1], periodic, boxsize, boxhalf);
+          if(dy > dist)
+            continue;
+          double dz = ngb_periodic(cur->center[2] - c[2], periodic, boxsize, boxhalf);
+          if(dz > dist)
+            continue;
+          dist += FACT1 * cur->len;
+          if(dx * dx + dy * dy + dz * dz > dist * dist)
+            continue;
+          no = cur->nextnode;
+        }
+    }
+  return numngb;
+}
+
+static inline void nearest_image(double *dx, double *dy, double *dz, int periodic, double boxsize)
+{
+  double boxhalf = 0.5 * boxsize;
+  if(!periodic)
+    return;
+  if(*dx > boxhalf)
+    *dx -= boxsize;
+  if(*dx < -boxhalf)
+    *dx += boxsize;
+  if(*dy > boxhalf)
+    *dy -= boxsize;
+  if(*dy < -boxhalf)
+    *dy += boxsize;
+  if(*dz > boxhalf)
+    *dz -= boxsize;
+  if(*dz < -boxhalf)
+    *dz += boxsize;
+}
+
+/* density() for Type-5 targets (density.c:125-704 with the BLACK_HOLES branches: 406-413,
+ * 521-532, 548-551, 613, 629; density_evaluate :763-765, 831-834, 879-886, 972-978): the h
+ * iteration against the gas, wanting DesNumNgb * BlackHoleNgbFactor neighbours, without the
+ * Newton step (that needs SphP[i].h.DhsmlDensityFactor: gas only, :613, 629); the sink's
+ * BH_Density, BH_Entropy (kernel-weighted mean entropy) and BH_SurroundingGasVel.
+ * hsml [n] in/out at the sinks' indices; outputs [nsink].  Returns iterations or -1. */
+int orc_sink_density(const orc_tree *t, const orc_dens_params *p, double ngbfactor, int nsink,
+                     const int *sink, const double *velpred, const double *entropy, double *hsml,
+                     double *numngb, double *bh_density, double *bh_entropy, double *bh_gasvel)
+{
+  int n = t->n;
+  double boxsize = p->BoxSize;
+  double *Left = (double *) calloc((size_t) (nsink > 0 ? nsink : 1), sizeof(double));
+  double *Right = (double *) calloc((size_t) (nsink > 0 ? nsink : 1), sizeof(double));
+  char *done = (char *) calloc((size_t) (nsink > 0 ? nsink : 1), 1);
+  int *ngblist = (int *) malloc((size_t) n * sizeof(int));
+  double desnumngb = p->DesNumNgb * ngbfactor; /* :548-551 */
+  int iter = 0, npleft;
+  do
+    {
+      npleft = 0;
+      for(int a = 0; a < nsink; a++)
+        {
+          if(done[a])
+            continue;
+          int i = sink[a];
+          const double *pos = t->pos + 3 * (size_t) i;
+          double h = hsml[i], h2 = h * h, hinv = 1.0 / h, hinv3 = hinv * hinv * hinv;
+          double rho = 0, wn = 0, smoothentr = 0, gasvel[3] = { 0, 0, 0 };
+          int nn = ngb_treefind(t, pos, h, NULL, 0, p->periodic, boxsize, ngblist);
+          for(int q = 0; q < nn; q++)
+            {
+              int j = ngblist[q];
+              if(t->mass[j] == 0) /* :831-834 */
+                continue;
+              double dx = pos[0] - t->pos[3 * j], dy = pos[1] - t->pos[3 * j + 1],
+                     dz = pos[2] - t->pos[3 * j + 2];
+              nearest_image(&dx, &dy, &dz, p->periodic, boxsize);
+              double r2 = dx * dx + dy * dy + dz * dz;
+              if(r2 < h2)
+                {
+                  double r = sqrt(r2), u = r * hinv, wk;
+                  if(u < 0.5)
+                    wk = hinv3 * (KERNEL_COEFF_1 + KERNEL_COEFF_2 * (u - 1) * u * u);
+                  else
+                    wk = hinv3 * KERNEL_COEFF_5 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+                  double mass_j = t->mass[j];
+                  rho += mass_j * wk;
+                  wn += NORM_COEFF * wk / hinv3;
+                  gasvel[0] += mass_j * wk * velpred[3 * j];
+                  gasvel[1] += mass_j * wk * velpred[3 * j + 1];
+                  gasvel[2] += mass_j * wk * velpred[3 * j + 2];
+                  smoothentr += mass_j * wk * entropy[j];
+                }
+            }
+          numngb[a] = wn;
+          bh_density[a] = rho;
+          if(rho > 0) /* :521-532 */
+            {
+              bh_entropy[a] = smoothentr / rho;
+              for(int k = 0; k < 3; k++)
+                bh_gasvel[3 * a + k] = gasvel[k] / rho;
+            }
+          else
+            {
+              bh_entropy[a] = smoothentr;
+              for(int k = 0; k < 3; k++)
+                bh_gasvel[3 * a + k] = gasvel[k];
+            }
+          /* :559-652 */
+          if(wn < (desnumngb - p->MaxNumNgbDeviation) ||
+             (wn > (desnumngb + p->MaxNumNgbDeviation) && h > (1.01 * p->MinGasHsml)))
+            {
+              npleft++;
+              if(Left[a] > 0 && Right[a] > 0)
+                if((Right[a] - Left[a]) < 1.0e-3 * Left[a])
+                  {
+                    npleft--;
+                    done[a] = 1;
+                    continue;
+                  }
+              if(wn < (desnumngb - p->MaxNumNgbDeviation))
+                Left[a] = h > Left[a] ? h : Left[a];
+              else
+                {
+                  if(Right[a] != 0)
+                    {
+                      if(h < Right[a])
+                        Right[a] = h;
+                    }
+                  else
+                    Right[a] = h;
+                }
+              if(Right[a] > 0 && Left[a] > 0)
+                h = pow(0.5 * (pow(Left[a], 3) + pow(Right[a], 3)), 1.0 / 3);
+              else
+                {
+                  if(Right[a] == 0 && Left[a] > 0)
+                    h *= 1.26; /* no Newton step for non-gas targets, :613 */
+                  if(Right[a] > 0 && Left[a] == 0)
+                    h /= 1.26;
+                }
+              if(h < p->MinGasHsml)
+                h = p->MinGasHsml;
+              hsml[i] = h;
+            }
+          else
+            done[a] = 1;
+        }
+      if(npleft > 0)
+        {
+          iter++;
+          if(iter > p->maxiter)
+            {
+              iter = -1;
+              break;
+            }
+        }
+    }
+  while(npleft > 0);
+  free(Left);
+  free(Right);
+  free(done);
+  free(ngblist);
+  return iter;
+}
+
+/* blackhole_evaluate (blackhole.c:794-1190), mode 0, for the flag bundle above.
+ * Per neighbour j within Hsml of sink i (both with mass > 0):
+ *   sink   (:935-1001)  closer than the accretion boundary (InnerBoundary for the central object,
+ *                       mass > 0.95 SMBHmass, else SofteningBndry) and not heavier: marked
+ *   dust   (:1004-1036) closer than InnerBoundary / SinkBoundary and bound (e_tot <= 0): marked
+ *   gas    (:1040-1160) kernel weight; the central object marks gas inside InnerBoundary; other
+ *                       sinks mark gas inside SinkBoundary only without ACCRETION_OF_DUST_ONLY
+ *                       (bound, or denser than CritDensity with ACCRETION_DENSITY); thermal
+ *                       feedback of the smaller sinks is spread with the kernel
+ * "marked" = SwallowID[j] = ID of the sink.  Two deliberate deviations from the reference text:
+ *   (1) a victim claimed by several sinks goes to the LARGEST ID, for all three kinds -- the
+ *       reference says so for gas (:1068, 1088, 1106) and lets the last sink of the active list win
+ *       for dust and sinks (:984-988, 1028: a result that depends on the list order);
+ *   (2) the dust branch computes e_tot with r = sqrt(r2) of the grain -- the reference reads `r`
+ *       there (:1023) before any assignment in that iteration (it is set in the gas branch only).
+ * dt_fac = Timebase_interval / hubble_a (:822); ascale = All.Time or 1. */
+void orc_blackhole_evaluate(const orc_tree *t, const orc_bh_params *p, int nsink, const int *sink,
+                            const unsigned int *id, const double *hsml, const int *timebin,
+                            const double *bh_mdot, const double *bh_density,
+                            const double *gas_density, unsigned int *swallowid,
+                            double *injected_energy)
+{
+  int n = t->n;
+  int *ngblist = (int *) malloc((size_t) n * sizeof(int));
+  for(int a = 0; a < nsink; a++)
+    {
+      int i = sink[a];
+      const double *pos = t->pos + 3 * (size_t) i, *velocity = t->vel + 3 * (size_t) i;
+      double mass = t->mass[i], h_i = hsml[i], h_i2 = h_i * h_i;
+      double rho = bh_density[a], mdot = bh_mdot[a];
+      double dt = (timebin[i] ? (1 << timebin[i]) : 0) * p->dt_fac;
+      unsigned int myid = id[i];
+      int central = mass > 0.95 * p->SMBHmass;
+      int nn = ngb_treefind_blackhole(t, pos, h_i, p->dust, p->periodic, p->BoxSize, ngblist);
+      for(int q = 0; q < nn; q++)
+        {
+          int j = ngblist[q];
+          if(!(t->mass[j] > 0) || !(mass > 0))
+            continue;
+          double dx = pos[0] - t->pos[3 * j], dy = pos[1] - t->pos[3 * j + 1],
+                 dz = pos[2] - t->pos[3 * j + 2];
+          nearest_image(&dx, &dy, &dz, p->periodic, p->BoxSize);
+          double r2 = dx * dx + dy * dy + dz * dz;
+          if(!(r2 < h_i2))
+            continue;
+          double vrel = 0;
+          for(int k = 0; k < 3; k++)
+            vrel += (t->vel[3 * j + k] - velocity[k]) * (t->vel[3 * j + k] - velocity[k]);
+          vrel = sqrt(vrel) / p->ascale;
+          if(t->type[j] == 5 && r2 > 0)
+            {
+              double acc_boundary = central ? p->InnerBoundary : p->SofteningBndry;
+              if(!(pow(r2, 0.5) > acc_boundary))
+                if(t->mass[j] <= mass && swallowid[j] < myid)
+                  swallowid[j] = myid;
+            }
+          if(p->dust && t->type[j] == 2 && r2 > 0)
+            {
+              double acc_boundary = central ? p->InnerBoundary : p->SinkBoundary;
+              if(pow(r2, 0.5) < acc_boundary)
+                {
+                  double etotal = vrel * vrel / 2. - mass / (sqrt(r2) + 1.e-20);
+                  if(etotal <= 0. && swallowid[j] < myid)
+                    swallowid[j] = myid;
+                }
+            }
+          if(t->type[j] == 0)
+            {
+              double r = sqrt(r2), hinv = 1 / h_i, hinv3 = hinv * hinv * hinv, u = r * hinv, wk;
+              if(u < 0.5)
+                wk = hinv3 * (KERNEL_COEFF_1 + KERNEL_COEFF_2 * (u - 1) * u * u);
+              else
+                wk = hinv3 * KERNEL_COEFF_5 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+              double etotal = vrel * vrel / 2. - mass / (r + 1.e-20);
+              if(central)
+                {
+                  if(r < p->InnerBoundary && swallowid[j] < myid)
+                    swallowid[j] = myid;
+                }
+              else if(!p->accretion_of_dust_only)
+                {
+                  if(r < p->SinkBoundary)
+                    {
+                      int ok = p->accretion_density ? (gas_density[j] >= p->CritDensity) : (etotal < 0.);
+                      if(ok && swallowid[j] < myid)
+                        swallowid[j] = myid;
+                    }
+                }
+              /* :1114-1150 TMP_FEEDBACK without FRACTION_OF_LSOLAR_FB: only the smaller sinks */
+              double energy = 0.;
+              if(mass < 0.95 * p->SMBHmass)
+                energy = p->FeedbackCoeff * pow(mass * p->UnitMass_in_g, 0.6667) * mdot *
+                         p->UnitMass_in_g * dt;
+              injected_energy[j] += energy * t->mass[j] * wk / rho;
+            }
+        }
+    }
+  free(ngblist);
+}
+
+/* blackhole_evaluate_swallow (blackhole.c:1201-1346), mode 0: every neighbour marked with the
+ * sink's ID is swallowed -- its mass and momentum are summed, its own mass (and BH_Mass) set to
+ * zero.  mass [n] and particle_bh_mass [n] (BH_Mass of sinks, else ignored) are modified.
+ * Outputs [nsink]: accreted mass, accreted BH mass, accreted dust mass, momentum [nsink][3];
+ * counts[3] = gas, sinks, dust swallowed. */
+void orc_blackhole_swallow(const orc_tree *t, const orc_bh_params *p, int nsink, const int *sink,
+                           const unsigned int *id, const double *hsml,
+                           const unsigned int *swallowid, double *mass, double *particle_bh_mass,
+                           double *acc_mass, double *acc_bhmass, double *acc_dustmass,
+                           double *acc_momentum, long long counts[3])
+{
+  int n = t->n;
+  int *ngblist = (int *) malloc((size_t) n * sizeof(int));
+  counts[0] = counts[1] = counts[2] = 0;
+  for(int a = 0; a < nsink; a++)
+    {
+      int i = sink[a];
+      const double *pos = t->pos + 3 * (size_t) i;
+      unsigned int myid = id[i];
+      double am = 0, ab = 0, ad = 0, mom[3] = { 0, 0, 0 };
+      int nn = ngb_treefind_blackhole(t, pos, hsml[i], p->dust, p->periodic, p->BoxSize, ngblist);
+      for(int q = 0; q < nn; q++)
+        {
+          int j = ngblist[q];
+          if(swallowid[j] != myid)
+            continue;
+          if(t->type[j] == 5)
+            {
+              am += mass[j];
+              ab += particle_bh_mass[j];
+              for(int k = 0; k < 3; k++)
+                mom[k] += mass[j] * t->vel[3 * j + k];
+              mass[j] = 0;
+              particle_bh_mass[j] = 0;
+              counts[1]++;
+            }
+          else if(t->type[j] == 2)
+            {
+              am += mass[j];
+              ad += mass[j];
+              for(int k = 0; k < 3; k++)
+                mom[k] += mass[j] * t->vel[3 * j + k];
+              mass[j] = 0;
+              counts[2]++;
+            }
+          else if(t->type[j] == 0)
+            {
+              am += mass[j];
+              for(int k = 0; k < 3; k++)
+                mom[k] += mass[j] * t->vel[3 * j + k];
+              mass[j] = 0.;
+              counts[0]++;
+            }
+        }
+      acc_mass[a] = am;
+      acc_bhmass[a] = ab;
+      acc_dustmass[a] = ad;
+      for(int k = 0; k < 3; k++)
+        acc_momentum[3 * a + k] = mom[k];
+    }
+  free(ngblist);
+}
+
+/* cooling_and_starformation (sfr_eff.c:82-947), the deterministic per-particle part that is active
+ * for the shipped bundle (COOLING, SFR, BH_FORM without JEANS_MASS_SF, BLACK_HOLES,
+ * BH_THERMALFEEDBACK) with the cooling function itself (DoCooling, cooling.c) left to the caller
+ * as unew -> unew (identity here):
+ *   flag   (:226-229, 459-462)  0 = the gas particle qualifies for conversion into a sink
+ *                               (Density >= CritPhysDensity in code units) unless its mass is 0
+ *   unew   (:486-488)           max(MinEgySpec, (A + dA/dt dt) / (gamma-1) rho^(gamma-1))
+ *          (:509-531)           + Injected_BH_Energy / Mass, capped at 5e9 K; the injection is consumed
+ *   dA/dt  (:582-594)           (unew (gamma-1) / rho^(gamma-1) - A) / dt, floor -0.5 A / dt
+ * Non-comoving (a3inv = 1).  The conversion itself (Type = 5, the random mass factor of :618) is
+ * the host's: it needs the GSL stream. */
+void orc_cooling_and_starformation(int nactive, const int *active, int ngas, const int *type,
+                                   const double *mass, const int *timebin, double timebase,
+                                   double CritPhysDensity_code, double MinEgySpec,
+                                   double u_to_temp_fac, const double *density,
+                                   const double *entropy, double *dtentropy,
+                                   double *injected_energy, int *flag_sink)
+{
+  for(int a = 0; a < nactive; a++)
+    {
+      int i = active[a];
+      if(i >= ngas || type[i] != 0)
+        continue;
+      double dt = (timebin[i] ? (1 << timebin[i]) : 0) * timebase;
+      int flag = 1;
+      if(density[i] >= CritPhysDensity_code)
+        flag = 0;
+      if(mass[i] == 0)
+        flag = 1;
+      flag_sink[i] = !flag;
+      if(flag == 1)
+        {
+          double unew = (entropy[i] + dtentropy[i] * dt) / GAMMA_MINUS1 * pow(density[i], GAMMA_MINUS1);
+          if(unew < MinEgySpec)
+            unew = MinEgySpec;
+          if(injected_energy[i])
+            {
+              if(mass[i] == 0)
+                injected_energy[i] = 0;
+              else
+                unew += injected_energy[i] / mass[i];
+              double temp = u_to_temp_fac * unew;
+              if(temp > 5.0e9)
+                unew = 5.0e9 / u_to_temp_fac;
+              injected_energy[i] = 0;
+            }
+          if(timebin[i] && dt > 0)
+            {
+              dtentropy[i] = (unew * GAMMA_MINUS1 / pow(density[i], GAMMA_MINUS1) - entropy[i]) / dt;
+              if(dtentropy[i] < -0.5 * entropy[i] / dt)
+                dtentropy[i] = -0.5 * entropy[i] / dt;
+            }
+        }
+    }
+}

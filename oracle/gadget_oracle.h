@@ -206,6 +206,44 @@ int orc_advance_timesteps(int n, int ngas, const orc_kick_params *p, int nactive
                           const double *hsml, const double *maxsignalvel, int *timebin,
                           int *ti_begstep, long long bincount[32], long long bincount_sph[32]);
 
+/* ---- "next" row N4: sink (black-hole) neighbour passes + the per-particle part of
+ * cooling_and_starformation, for the shipped flag bundle (gadget_oracle.c has the flag list) ---- */
+typedef struct
+{
+  double BoxSize;
+  int periodic;
+  double ascale;            /* All.Time when comoving, else 1 (blackhole.c:89-95) */
+  double dt_fac;            /* All.Timebase_interval / hubble_a (:822) */
+  double SMBHmass, InnerBoundary, SinkBoundary, SofteningBndry;   /* All.* */
+  double CritDensity;       /* All.CritOverDensity * UnitLength_in_cm^3 / UnitMass_in_g (:1099) */
+  double FeedbackCoeff;     /* All.BlackHoleFeedbackFactor * 6.67e-8 * pow(4.*3.1415/3.*5., 0.3333)
+                               / All.UnitEnergy_in_cgs (:1138-1139) */
+  double UnitMass_in_g;
+  int dust;                   /* -DDUST */
+  int accretion_of_dust_only; /* -DACCRETION_OF_DUST_ONLY */
+  int accretion_density;      /* -DACCRETION_DENSITY */
+} orc_bh_params;
+
+int orc_sink_density(const orc_tree *t, const orc_dens_params *p, double ngbfactor, int nsink,
+                     const int *sink, const double *velpred, const double *entropy, double *hsml,
+                     double *numngb, double *bh_density, double *bh_entropy, double *bh_gasvel);
+void orc_blackhole_evaluate(const orc_tree *t, const orc_bh_params *p, int nsink, const int *sink,
+                            const unsigned int *id, const double *hsml, const int *timebin,
+                            const double *bh_mdot, const double *bh_density,
+                            const double *gas_density, unsigned int *swallowid,
+                            double *injected_energy);
+void orc_blackhole_swallow(const orc_tree *t, const orc_bh_params *p, int nsink, const int *sink,
+                           const unsigned int *id, const double *hsml,
+                           const unsigned int *swallowid, double *mass, double *particle_bh_mass,
+                           double *acc_mass, double *acc_bhmass, double *acc_dustmass,
+                           double *acc_momentum, long long counts[3]);
+void orc_cooling_and_starformation(int nactive, const int *active, int ngas, const int *type,
+                                   const double *mass, const int *timebin, double timebase,
+                                   double CritPhysDensity_code, double MinEgySpec,
+                                   double u_to_temp_fac, const double *density,
+                                   const double *entropy, double *dtentropy,
+                                   double *injected_energy, int *flag_sink);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int nthreads);
 

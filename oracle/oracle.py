@@ -301,6 +301,95 @@ class Tree:
         return out
 
 
+class BhParams(C.Structure):
+    """orc_bh_params (gadget_oracle.h): the sink passes of the shipped flag bundle"""
+    _fields_ = [("BoxSize", C.c_double), ("periodic", C.c_int), ("ascale", C.c_double),
+                ("dt_fac", C.c_double), ("SMBHmass", C.c_double), ("InnerBoundary", C.c_double),
+                ("SinkBoundary", C.c_double), ("SofteningBndry", C.c_double),
+                ("CritDensity", C.c_double), ("FeedbackCoeff", C.c_double),
+                ("UnitMass_in_g", C.c_double), ("dust", C.c_int),
+                ("accretion_of_dust_only", C.c_int), ("accretion_density", C.c_int)]
+
+
+def sink_density(tree, params, ngbfactor, sinks, velpred, entropy, hsml):
+    """density() for Type-5 targets (density.c BLACK_HOLES branches).  Returns dict."""
+    sinks = _i32(sinks)
+    ns = len(sinks)
+    vp = np.zeros((tree.n, 3))
+    vp[:len(velpred)] = velpred
+    en = np.zeros(tree.n)
+    en[:len(entropy)] = entropy
+    out = dict(hsml=_f64(hsml).copy(), numngb=np.zeros(ns), density=np.zeros(ns),
+               entropy=np.zeros(ns), gasvel=np.zeros((ns, 3)))
+    L = lib()
+    L.orc_sink_density.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int] + [C.c_void_p] * 8
+    it = L.orc_sink_density(tree.h, C.byref(params), float(ngbfactor), ns, _p(sinks), _p(vp), _p(en),
+                            _p(out["hsml"]), _p(out["numngb"]), _p(out["density"]),
+                            _p(out["entropy"]), _p(out["gasvel"]))
+    out["iterations"] = it
+    return out
+
+
+def blackhole_evaluate(tree, params, sinks, ids, hsml, timebin, mdot, bh_density, gas_density,
+                       swallowid, injected):
+    """blackhole_evaluate (blackhole.c:794) over the sinks in list order; swallowid [n] (uint32)
+    and injected [n] are updated and returned (copies)."""
+    sinks = _i32(sinks)
+    sw = np.ascontiguousarray(swallowid, np.uint32).copy()
+    inj = np.zeros(tree.n)
+    inj[:len(injected)] = injected
+    gd = np.zeros(tree.n)
+    gd[:len(gas_density)] = gas_density
+    ids = np.ascontiguousarray(ids, np.uint32)
+    L = lib()
+    L.orc_blackhole_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    L.orc_blackhole_evaluate.restype = None
+    L.orc_blackhole_evaluate(tree.h, C.byref(params), len(sinks), _p(sinks), _p(ids), _p(_f64(hsml)),
+                             _p(_i32(timebin)), _p(_f64(mdot)), _p(_f64(bh_density)), _p(gd), _p(sw),
+                             _p(inj))
+    return sw, inj[:len(injected)]
+
+
+def blackhole_swallow(tree, params, sinks, ids, hsml, swallowid, particle_bh_mass):
+    """blackhole_evaluate_swallow (blackhole.c:1201).  The tree's mass array IS modified (victims
+    are set to zero), as the reference does.  Returns dict."""
+    sinks = _i32(sinks)
+    ns = len(sinks)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    sw = np.ascontiguousarray(swallowid, np.uint32)
+    pbh = _f64(particle_bh_mass).copy()
+    out = dict(acc_mass=np.zeros(ns), acc_bhmass=np.zeros(ns), acc_dustmass=np.zeros(ns),
+               acc_momentum=np.zeros((ns, 3)), counts=np.zeros(3, np.int64), bh_mass=pbh)
+    L = lib()
+    L.orc_blackhole_swallow.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 11
+    L.orc_blackhole_swallow.restype = None
+    L.orc_blackhole_swallow(tree.h, C.byref(params), ns, _p(sinks), _p(ids), _p(_f64(hsml)), _p(sw),
+                            _p(tree.mass), _p(pbh), _p(out["acc_mass"]), _p(out["acc_bhmass"]),
+                            _p(out["acc_dustmass"]), _p(out["acc_momentum"]), _p(out["counts"]))
+    out["mass"] = tree.mass
+    return out
+
+
+def cooling_and_starformation(active, ngas, ptype, mass, timebin, timebase, crit_density, min_egy,
+                              u_to_temp_fac, density, entropy, dtentropy, injected):
+    """the deterministic per-particle part of cooling_and_starformation (sfr_eff.c:82-947) with the
+    cooling function as identity.  Returns (dtentropy, injected, flag_sink)."""
+    active = _i32(active)
+    dte = _f64(dtentropy).copy()
+    inj = _f64(injected).copy()
+    flag = np.zeros(len(mass), np.int32)
+    L = lib()
+    L.orc_cooling_and_starformation.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                                C.c_double] + [C.c_void_p] * 5
+    L.orc_cooling_and_starformation.restype = None
+    L.orc_cooling_and_starformation(len(active), _p(active), int(ngas), _p(_i32(ptype)), _p(_f64(mass)),
+                                    _p(_i32(timebin)), float(timebase), float(crit_density),
+                                    float(min_egy), float(u_to_temp_fac), _p(_f64(density)),
+                                    _p(_f64(entropy)), _p(dte), _p(inj), _p(flag))
+    return dte, inj, flag[:ngas]
+
+
 def gravity_finish(acc, G, pos=None, gravpm=None, comoving_fac=0.0):
     """The post-pass of gravity_tree() over the active particles (gravtree.c:362-403), in the
     reference's order.  acc: G-less tree accelerations [n,3]; pos: P[].Pos (only with comoving_fac);

@@ -231,3 +231,48 @@ class ShardSet:
     def close(self):
         for fp in self.fp:
             fp.close()
+
+
+class SinkProblem:
+    """A Problem with a few Type-5 sinks and Type-2 dust grains (config c5's ingredients): some DM
+    particles are re-typed, one sink is the heavy central object.  Parameters of the shipped flag
+    bundle's sink passes (blackhole.c) in code units."""
+
+    def __init__(self, ng=8, periodic=1, nsink=6, ndust=200, seed=5):
+        pr = Problem(ng=ng, gas=True, periodic=periodic)
+        self.pr = pr
+        rng = np.random.default_rng(seed)
+        n, ngas = pr.n, pr.ngas
+        dm = np.arange(ngas, n)
+        pick = rng.choice(dm, nsink + ndust, replace=False)
+        self.sinks = np.sort(pick[:nsink]).astype(np.int32)
+        self.dust = np.sort(pick[nsink:])
+        typ = pr.ic["type"].copy()
+        typ[self.sinks] = 5
+        typ[self.dust] = 2
+        pr.ic["type"] = typ
+        mass = pr.ic["mass"].copy()
+        mass[self.sinks] = 40.0 * mass[ngas]           # heavier than anything around
+        mass[self.sinks[0]] = 400.0 * mass[ngas]       # the central object
+        pr.ic["mass"] = mass
+        pr.ic["vel"] = 0.05 * pr.ic["vel"]             # slow: some neighbours are bound
+        pr.velpred = pr.ic["vel"][:ngas] + 0.0
+        self.ids = (np.arange(n, dtype=np.uint32) * 7 + 11).astype(np.uint32)   # unique, unordered
+        self.hsml = pr.hsml0.copy()
+        self.hsml[self.sinks] = 2.6 * pr.ic["spacing"]
+        self.bh_mass = np.zeros(n)
+        self.bh_mass[self.sinks] = 0.5 * mass[self.sinks]
+        self.mdot = 1.0e-3 * (1 + rng.random(nsink))
+        self.SMBHmass = mass[self.sinks[0]]
+        sp = pr.ic["spacing"]
+        self.par = dict(BoxSize=pr.box, periodic=periodic, ascale=1.0, dt_fac=pr.timebase,
+                        SMBHmass=self.SMBHmass, InnerBoundary=2.0 * sp, SinkBoundary=1.5 * sp,
+                        SofteningBndry=2.4 * sp, CritDensity=0.0, FeedbackCoeff=3.0e-9,
+                        UnitMass_in_g=1.989e33, dust=1, accretion_of_dust_only=1,
+                        accretion_density=1)
+
+    def params(self, cls, **over):
+        p = cls()
+        for k, v in {**self.par, **over}.items():
+            setattr(p, k, v)
+        return p

@@ -1662,12 +1662,15 @@ def test_config_c3_128cubed_shortrange_tree_and_sph_sampled():
 
 
 def test_config_c5_size_256cubed_one_step_sampled():
-    """The particle load of c5 (256^3 DM + 256^3 gas = 33.5 million; its star-formation and
-    black-hole loops are out of scope): one full force step from the 25 GB resident state, gravity
-    checked against the oracle on a sample, SPH through the neighbour window and momentum balance.
-    Guards the 64-bit offsets of every kernel."""
+    """The particle load of c5 (256^3 DM + 256^3 gas = 33.5 million, 300 of the DM particles being
+    sinks and 3000 dust grains): one full force step from the 25 GB resident state, gravity checked
+    against the oracle on a sample, SPH through the neighbour window and momentum balance, then the
+    black-hole neighbour loops of the 300 sinks against the oracle.  Guards the 64-bit offsets of
+    every kernel."""
     B = bindings()
-    pr = Problem(ng=256, gas=True, periodic=1)
+    from common import SinkProblem
+    sp = SinkProblem(ng=256, periodic=1, nsink=300, ndust=3000)   # c5's sinks and dust among the DM
+    pr = sp.pr
     n, ng = pr.n, pr.ngas
     fp = pr.device()
     pr.device_tree(fp)
@@ -1695,6 +1698,35 @@ def test_config_c5_size_256cubed_one_step_sampled():
     T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
     assert np.array_equal(cost[sample], ocost)
     assert relerr(acc[sample], oacc) < TOL
+    # ---- the neighbour loops of blackhole.c for the 300 sinks ("next" row N4) on the same state:
+    # density of the sinks, marking + feedback, swallowing -- against the oracle on the same tree
+    hs = fp.get_field(B.F_HSML)
+    hs[sp.sinks] = sp.hsml[sp.sinks]
+    fp.set_field(B.F_HSML, hs)
+    gas_density = fp.get_field(B.F_DENSITY)
+    par = dict(accretion_of_dust_only=0, CritDensity=float(np.median(gas_density)))
+    T.hsml = hs
+    od = O.sink_density(T, pr.o_dens(), 1.5, sp.sinks, pr.velpred, pr.entropy, hs)
+    gd = fp.sink_density(pr.g_dens(), 1.5, sp.sinks, hs[sp.sinks])
+    assert gd["iterations"] == od["iterations"]
+    assert relerr(gd["hsml"], od["hsml"][sp.sinks]) < 1e-13
+    assert relerr(gd["density"], od["density"]) < TOL
+    fp.sink_reset()
+    osw, oinj = O.blackhole_evaluate(T, sp.params(O.BhParams, **par), sp.sinks, sp.ids, od["hsml"],
+                                     pr.timebin, sp.mdot, od["density"], gas_density,
+                                     np.zeros(n, np.uint32), np.zeros(ng))
+    fp.blackhole_evaluate(sp.params(B.BhParams, **par), sp.sinks, sp.ids[sp.sinks], sp.mdot,
+                          gd["density"])
+    gsw, ginj = fp.sink_marks()
+    assert np.array_equal(gsw, osw) and (osw > 0).sum() > 300
+    assert np.abs(ginj - oinj).max() <= 1e-11 * np.abs(oinj).max()
+    oo = O.blackhole_swallow(T, sp.params(O.BhParams, **par), sp.sinks, sp.ids, od["hsml"], osw,
+                             sp.bh_mass)
+    go = fp.blackhole_swallow(sp.params(B.BhParams, **par), sp.sinks, sp.ids[sp.sinks],
+                              sp.bh_mass[sp.sinks])
+    assert np.array_equal(go["counts"], oo["counts"])
+    assert np.abs(go["acc_mass"] - oo["acc_mass"]).max() <= 1e-13 * oo["acc_mass"].max()
+    assert np.array_equal(fp.get_field(B.F_MASS), T.mass)
 
 
 @pytest.mark.parametrize("ng,pmgrid", [(16, 32), (32, 128)])

@@ -422,3 +422,117 @@ def test_gravity_tree_post_pass_old_acc_and_g_by_hand():
     old, g = O.gravity_finish(acc, 2.0, pos=np.array([[2.0, 0.0, -8.0]]), comoving_fac=0.5)
     assert old[0] == 4.0 and np.array_equal(g, [[8.0, 0.0, 0.0]])
     assert np.array_equal(acc, [[3.0, 0.0, 4.0]])          # inputs untouched
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row N4: the sink passes against all-pairs numpy (no tree, no neighbour search)
+# ------------------------------------------------------------------------------------------------
+def _wrap(d, box, periodic):
+    return d - box * np.round(d / box) if periodic else d
+
+
+def _kernel_w(r, h):
+    u = r / h
+    hinv3 = 1.0 / h ** 3
+    return np.where(u < 0.5, hinv3 * (2.546479089470 + 15.278874536822 * (u - 1) * u * u),
+                    hinv3 * 5.092958178941 * (1.0 - u) ** 3)
+
+
+@pytest.mark.parametrize("periodic", [0, 1])
+@pytest.mark.parametrize("dust_only,acc_density", [(1, 1), (0, 1), (0, 0)])
+def test_sink_passes_against_all_pairs(periodic, dust_only, acc_density):
+    from common import SinkProblem
+    sp = SinkProblem(ng=8, periodic=periodic)
+    pr = sp.pr
+    n, ngas = pr.n, pr.ngas
+    pos, vel, mass, typ = pr.ic["pos"], pr.ic["vel"], pr.ic["mass"].copy(), pr.ic["type"]
+    gas_density = 0.5 + np.random.default_rng(3).random(ngas)
+    par = sp.params(O.BhParams, accretion_of_dust_only=dust_only, accretion_density=acc_density,
+                    CritDensity=1.0)
+    T = O.Tree(pos, vel, mass, typ, pr.force_soft, hsml=sp.hsml, extent=pr.extent)
+    # ---- sink density: all-pairs kernel sums at the converged h ----
+    sd = O.sink_density(T, pr.o_dens(), 1.5, sp.sinks, pr.velpred, pr.entropy, sp.hsml)
+    assert sd["iterations"] >= 0
+    for a, i in enumerate(sp.sinks):
+        h = sd["hsml"][i]
+        d = _wrap(pos[i] - pos[:ngas], pr.box, periodic)
+        r = np.linalg.norm(d, axis=1)
+        m = (r < h) & (mass[:ngas] > 0)
+        w = _kernel_w(r[m], h)
+        rho = (mass[:ngas][m] * w).sum()
+        assert abs(sd["density"][a] - rho) < 1e-12 * rho
+        assert abs(sd["numngb"][a] - (4.188790204786 * w * h ** 3).sum()) < 1e-10
+        assert abs(sd["numngb"][a] - 1.5 * pr.des_ngb) <= pr.max_dev + 1e-9   # BlackHoleNgbFactor
+        assert abs(sd["entropy"][a] - (mass[:ngas][m] * w * pr.entropy[m]).sum() / rho) < 1e-12
+        gv = (mass[:ngas][m, None] * w[:, None] * pr.velpred[m]).sum(axis=0) / rho
+        assert np.abs(sd["gasvel"][a] - gv).max() < 1e-12 * max(1e-3, np.abs(gv).max())
+    # ---- marking + feedback ----
+    sw, inj = O.blackhole_evaluate(T, par, sp.sinks, sp.ids, sp.hsml, pr.timebin, sp.mdot,
+                                   sd["density"], gas_density, np.zeros(n, np.uint32), np.zeros(ngas))
+    want_sw = np.zeros(n, np.uint32)
+    want_inj = np.zeros(ngas)
+    for a, i in enumerate(sp.sinks):
+        h = sp.hsml[i]
+        d = _wrap(pos[i] - pos, pr.box, periodic)
+        r2 = (d * d).sum(axis=1)
+        r = np.sqrt(r2)
+        vrel = np.linalg.norm(vel - vel[i], axis=1)
+        central = mass[i] > 0.95 * sp.SMBHmass
+        cand = (r2 < h * h) & (mass > 0)
+        etot = vrel ** 2 / 2 - mass[i] / (r + 1e-20)
+        bh = cand & (typ == 5) & (r2 > 0) & ~(r > (par.InnerBoundary if central else par.SofteningBndry)) \
+            & (mass <= mass[i])
+        du = cand & (typ == 2) & (r2 > 0) & (r < (par.InnerBoundary if central else par.SinkBoundary)) \
+            & (etot <= 0)
+        if central:
+            ga = cand & (typ == 0) & (r < par.InnerBoundary)
+        elif dust_only:
+            ga = np.zeros(n, bool)
+        else:
+            ok = (np.concatenate([gas_density, np.zeros(n - ngas)]) >= par.CritDensity) if acc_density \
+                else (etot < 0)
+            ga = cand & (typ == 0) & (r < par.SinkBoundary) & ok
+        claim = bh | du | ga
+        want_sw[claim] = np.maximum(want_sw[claim], sp.ids[i])
+        g = cand[:ngas] & (typ[:ngas] == 0)
+        if not central:
+            dt = (1 << pr.timebin[i]) * par.dt_fac
+            energy = par.FeedbackCoeff * (mass[i] * par.UnitMass_in_g) ** 0.6667 * sp.mdot[a] * \
+                par.UnitMass_in_g * dt
+            want_inj[g] += energy * mass[:ngas][g] * _kernel_w(r[:ngas][g], h) / sd["density"][a]
+    assert np.array_equal(sw, want_sw)
+    assert (want_sw > 0).sum() > 5                       # the case really marks victims
+    assert np.abs(inj - want_inj).max() <= 1e-12 * np.abs(want_inj).max()
+    # ---- swallowing: what each sink gets is what was marked for it ----
+    before = mass.copy()
+    out = O.blackhole_swallow(T, par, sp.sinks, sp.ids, sp.hsml, sw, sp.bh_mass)
+    for a, i in enumerate(sp.sinks):
+        v = np.where(sw == sp.ids[i])[0]
+        assert abs(out["acc_mass"][a] - before[v].sum()) <= 1e-15 * max(before[v].sum(), 1e-300)
+        assert abs(out["acc_dustmass"][a] - before[v[typ[v] == 2]].sum()) < 1e-18
+        assert abs(out["acc_bhmass"][a] - sp.bh_mass[v[typ[v] == 5]].sum()) < 1e-18
+        mom = (before[v, None] * vel[v]).sum(axis=0)
+        assert np.abs(out["acc_momentum"][a] - mom).max() <= 1e-14 * max(np.abs(mom).max(), 1e-300)
+    assert np.all(T.mass[sw > 0] == 0) and np.array_equal(T.mass[sw == 0], before[sw == 0])
+    assert out["counts"].sum() == (sw > 0).sum()
+    # total mass is conserved by the pair of passes
+    assert abs(out["acc_mass"].sum() + T.mass.sum() - before.sum()) < 1e-14 * before.sum()
+
+
+def test_cooling_and_starformation_update_by_hand():
+    """sfr_eff.c:486-488, 509-531, 582-594 with gamma = 7/5 on numbers one can check: A = 2,
+    dA/dt = 0.5, rho = 32 (rho^0.4 = 4), dt = 2^3 * 0.25 = 2 -> u = (2 + 1) / 0.4 * 4 = 30; injected
+    energy 6 on mass 2 -> u = 33 -> dA/dt = (33 * 0.4 / 4 - 2) / 2 = 0.65.  A particle denser than the
+    threshold is flagged for conversion and left alone; a strongly cooling one is held at -A/(2 dt)."""
+    typ = np.zeros(3, np.int32)
+    mass = np.array([2.0, 2.0, 2.0])
+    tb = np.array([3, 3, 3], np.int32)
+    dens = np.array([32.0, 1000.0, 32.0])
+    ent = np.array([2.0, 2.0, 2.0])
+    dte = np.array([0.5, 0.5, -5.0])
+    inj = np.array([6.0, 1.0, 0.0])
+    d, i2, flag = O.cooling_and_starformation(np.arange(3), 3, typ, mass, tb, 0.25, 500.0, 0.0, 1.0,
+                                              dens, ent, dte, inj)
+    assert abs(d[0] - 0.65) < 1e-15 and i2[0] == 0 and flag[0] == 0
+    assert flag[1] == 1 and d[1] == 0.5 and i2[1] == 1.0          # qualifies as a sink: untouched
+    assert d[2] == -0.5 * 2.0 / 2.0 and flag[2] == 0              # floor of sfr_eff.c:590-591
