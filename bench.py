@@ -186,13 +186,30 @@ def main():
             dist.all_gather_into_tensor(out, t)
             return out.numpy().tobytes()
 
-        dom = S.DomainRank(fp, rank, world, bcast, transport=transport, allgather=allgather_bytes)
+        rccl_error = None
+        if transport == "rccl":
+            # every rank must end up on the same transport: agree after the connect attempt
+            try:
+                dom = S.DomainRank(fp, rank, world, bcast, transport="rccl")
+                ok = 1.0
+            except Exception as e:   # noqa: BLE001 -- reported in the JSON line
+                rccl_error, ok = str(e), 0.0
+            t = torch.tensor([ok], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if float(t.item()) < 0.5:
+                transport = "host"
+                rccl_error = rccl_error or "another rank could not connect"
+                sys.stderr.write("bench: RCCL unavailable (%s): exchanges staged through the host\n"
+                                 % rccl_error)
+        if transport != "rccl":
+            dom = S.DomainRank(fp, rank, world, bcast, transport="host", allgather=allgather_bytes)
         fp.dd_set_domain(*tree_args)
         fp.dd_set_splits(splits)
         fp.dd_set_ghost_margin(1.5)
         parallelism = ("Peano-Hilbert domain decomposition over %d GPUs: migration, locally "
                        "essential trees and SPH ghosts over RCCL (%s), one merged tree per rank"
-                       % (world, "through the host + gloo (rehearsal)" if transport != "rccl"
+                       % (world, "NOT AVAILABLE (%s): exchanges staged through the host + gloo"
+                          % (rccl_error or "rehearsal") if transport != "rccl"
                           else "lib: " + B.dd_rccl_library()))
     for fid in (B.F_TIMEBIN, B.F_TI_BEGSTEP, B.F_TI_CURRENT):
         fp.set_field(fid, np.zeros(fp.n, np.int32))
