@@ -233,3 +233,117 @@ def test_rccl_path_single_rank():
                    pr.ti_begstep, pr.hsml0)
     assert relerr(fp.get_field(B.F_DENSITY), od["density"][:pr.ngas]) < TOL
     fp.close()
+
+
+@pytest.mark.parametrize("variant", ["unequal", "adaptive", "shortrange", "subset", "tiny", "plummer"])
+def test_sharded_gravity_variants(variant):
+    """The locally essential trees under the reference's other opening rules and edge cases: mixed
+    softenings (forcetree.c:2108-2124) and ADAPTIVE_GRAVSOFT_FORGAS (:2125-2139), the short-range walk
+    of a TreePM build, an active subset (sub-step: inactive particles are sources only), more shards
+    than a tiny problem can fill (empty shards take part in every exchange), a strongly clustered
+    non-periodic set.  Counts exact against the single tree every time."""
+    B = bindings()
+    kw = dict(ng=10, gas=True, periodic=1)
+    nsh = 4
+    if variant == "unequal":
+        kw["unequal"] = True
+    if variant == "tiny":
+        kw = dict(ng=3, gas=True, periodic=1)          # 54 particles on 8 shards
+        nsh = 8
+    if variant == "plummer":
+        from common import ics
+        kw = dict(periodic=0, ic=ics.make_plummer(3000, gas_fraction=0.3))
+        nsh = 5
+    pr = Problem(**kw)
+    n = pr.n
+    rng = np.random.default_rng(17)
+    old = 0.3 + 2.0 * rng.random(n)
+    S = ShardSet(pr, nsh, fields={"oldacc": old})
+    try:
+        T = pr.oracle_tree()
+        tg = np.arange(n, dtype=np.int32)
+        walk, okind, rc = B.WALK_NEWTON, "newton", {}
+        if variant == "adaptive":
+            S.each(lambda fp: fp.set_adaptive_gravsoft(True))
+            T.adaptive_gravsoft()
+        if variant == "shortrange":
+            asmth = 1.25 * pr.box / 16
+            rc = dict(rcut=4.5 * asmth, asmth=asmth)
+            walk, okind = B.WALK_SHORTRANGE, "shortrange"
+        if variant == "subset":
+            tg = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+            for r, fp in enumerate(S.fp):
+                loc = np.nonzero(np.isin(S.gid[r], tg))[0].astype(np.int32)
+                fp.set_active(loc)
+        for theta in (pr.theta, 0.0):
+            if rc:
+                oacc, ocost = T.gravity(pr.o_grav(theta, **rc), tg, old, kind=okind)
+                S.run.gravity(pr.g_grav(theta, rc["rcut"], rc["asmth"]), walk)
+            else:
+                oacc, ocost = T.gravity(pr.o_grav(theta), tg, old)
+                S.run.gravity(pr.g_grav(theta), walk)
+            assert np.array_equal(S.get_field(B.F_GRAVCOST)[tg], ocost), (variant, theta)
+            assert relerr(S.get_field(B.F_GRAVACCEL)[tg], oacc) < TOL
+        if variant == "tiny":
+            assert min(len(g) for g in S.gid) <= 7
+    finally:
+        S.close()
+
+
+@pytest.mark.parametrize("variant", ["subset", "tiny", "nonperiodic-clustered"])
+def test_sharded_sph_variants(variant):
+    """Ghost exchange on a sub-step (active subset: inactive gas particles are neighbours with their
+    current state), with nearly empty shards, and on a clustered non-periodic set."""
+    B = bindings()
+    kw = dict(ng=10, gas=True, periodic=1)
+    nsh = 4
+    if variant == "tiny":
+        kw, nsh = dict(ng=4, gas=True, periodic=1), 8
+    if variant == "nonperiodic-clustered":
+        from common import ics
+        kw, nsh = dict(periodic=0, ic=ics.make_plummer(4000, gas_fraction=0.5)), 3
+    pr = Problem(**kw)
+    ng = pr.ngas
+    S = ShardSet(pr, nsh)
+    try:
+        S.each(lambda fp: fp.dd_set_ghost_margin(3.0))
+        act = np.arange(ng, dtype=np.int32)
+        S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
+        if variant == "subset":
+            # converge everybody first (full step), then re-evaluate a third of them
+            S.run.density(pr.g_dens())
+            hs = S.get_field(B.F_HSML)
+            pr.hsml0 = hs.copy()
+            act = np.sort(np.random.default_rng(2).choice(ng, ng // 3, replace=False)).astype(np.int32)
+            for r, fp in enumerate(S.fp):
+                fp.set_active(np.nonzero(np.isin(S.gid[r], act))[0].astype(np.int32))
+            S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
+        S.run.density(pr.g_dens())
+        S.each(lambda fp: fp.update_hmax())
+        S.run.hydro(pr.g_hydro())
+        T = pr.oracle_tree(hsml=pr.hsml0)
+        full = np.arange(ng, dtype=np.int32)
+        if variant == "subset":
+            # the oracle's state of the inactive particles = the converged full step
+            od0 = T.density(pr.o_dens(), full, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                            pr.ti_begstep, pr.hsml0)
+            T.update_hmax(full, od0["hsml"], od0["divvel"])
+            od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                           pr.ti_begstep, od0["hsml"])
+            for k in ("hsml", "density", "pressure", "dhsmlfac", "divvel", "curlvel"):
+                od0[k][act] = od[k][act]
+            od = od0
+        else:
+            od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                           pr.ti_begstep, pr.hsml0)
+        T.update_hmax(full, od["hsml"], od["divvel"])
+        oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
+                     od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
+        assert relerr(S.get_field(B.F_DENSITY)[act], od["density"][act]) < 1e-9
+        assert relerr(S.get_field(B.F_HSML)[act], od["hsml"][act]) < 1e-9
+        st = S.each(lambda fp: fp.stats())
+        assert sum(s["hydro_pairs"] for s in st) == oh["npairs"]
+        ha = S.get_field(B.F_HYDROACCEL)[act]
+        assert np.abs(ha - oh["hydroaccel"][act]).max() < 1e-9 * np.abs(oh["hydroaccel"][act]).max()
+    finally:
+        S.close()
