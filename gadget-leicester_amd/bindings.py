@@ -704,6 +704,45 @@ class ForcePath:
 
 # ---- multi-GPU module-level helpers ----
 DD_MIGRATE, DD_GRAVITY, DD_DENSITY, DD_HYDRO = 1, 2, 3, 4
+DD_SINK_DENSITY, DD_BH_EVALUATE, DD_BH_SWALLOW = 5, 6, 7
+
+
+class DdSinkArgs(C.Structure):
+    """ghip_dd_sink_args (include/ghip.h): the sink passes on a multi-GPU shard"""
+    _fields_ = [("dens", C.POINTER(DensParams)), ("ngb_factor", C.c_double),
+                ("bh", C.POINTER(BhParams)), ("nsink", C.c_int), ("sink_idx", C.c_void_p),
+                ("sink_id", C.c_void_p), ("hsml", C.c_void_p), ("numngb", C.c_void_p),
+                ("bh_density", C.c_void_p), ("bh_entropy", C.c_void_p), ("bh_gasvel", C.c_void_p),
+                ("bh_mdot", C.c_void_p), ("bh_density_in", C.c_void_p),
+                ("sink_bh_mass", C.c_void_p), ("acc_mass", C.c_void_p), ("acc_bhmass", C.c_void_p),
+                ("acc_dustmass", C.c_void_p), ("acc_momentum", C.c_void_p), ("counts", C.c_void_p)]
+
+
+def dd_sink_args(sinks, sink_ids=None, dens=None, ngb_factor=1.0, bh=None, hsml=None, mdot=None,
+                 bh_density=None, sink_bh_mass=None):
+    """(args, arrays): a filled DdSinkArgs and the dict of numpy arrays it points into -- inputs
+    copied, outputs allocated; keep `arrays` alive until the operation has finished."""
+    ns = len(sinks)
+    f64 = lambda v: None if v is None else np.ascontiguousarray(v, np.float64).copy()
+    a = dict(sink_idx=np.ascontiguousarray(sinks, np.int32),
+             sink_id=None if sink_ids is None else np.ascontiguousarray(sink_ids, np.uint32),
+             hsml=f64(hsml), numngb=np.zeros(ns), density=np.zeros(ns), entropy=np.zeros(ns),
+             gasvel=np.zeros((ns, 3)), mdot=f64(mdot), bh_density_in=f64(bh_density),
+             bh_mass=f64(sink_bh_mass), acc_mass=np.zeros(ns), acc_bhmass=np.zeros(ns),
+             acc_dustmass=np.zeros(ns), acc_momentum=np.zeros((ns, 3)), counts=np.zeros(3, np.int64),
+             _dens=dens, _bh=bh)
+    A = DdSinkArgs()
+    A.dens = C.pointer(dens) if dens is not None else None
+    A.ngb_factor = float(ngb_factor)
+    A.bh = C.pointer(bh) if bh is not None else None
+    A.nsink = ns
+    vp = lambda v: None if v is None else v.ctypes.data
+    A.sink_idx, A.sink_id, A.hsml = vp(a["sink_idx"]), vp(a["sink_id"]), vp(a["hsml"])
+    A.numngb, A.bh_density, A.bh_entropy = vp(a["numngb"]), vp(a["density"]), vp(a["entropy"])
+    A.bh_gasvel, A.bh_mdot, A.bh_density_in = vp(a["gasvel"]), vp(a["mdot"]), vp(a["bh_density_in"])
+    A.sink_bh_mass, A.acc_mass, A.acc_bhmass = vp(a["bh_mass"]), vp(a["acc_mass"]), vp(a["acc_bhmass"])
+    A.acc_dustmass, A.acc_momentum, A.counts = vp(a["acc_dustmass"]), vp(a["acc_momentum"]), vp(a["counts"])
+    return A, a
 
 
 def dd_rccl_unique_id():

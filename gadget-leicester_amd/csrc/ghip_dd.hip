@@ -39,6 +39,9 @@
 int ghip_dd_build_gas_tree(ghip_ctx *ctx);
 int ghip_dd_refresh_ghosts(ghip_ctx *ctx);
 void ghip_dd_comm_release(ghip_ctx *ctx);
+// sink.hip
+int ghip_dd_sink_begin(ghip_ctx *ctx, int op);
+int ghip_dd_sink_step(ghip_ctx *ctx);
 extern "C" int ghip_dd_exchange(ghip_ctx *ctx);
 
 #define DD_OP_MIGRATE 1
@@ -943,27 +946,8 @@ __global__ void k_ghost_growth(int nt, const int *__restrict__ tgt, const int *_
 // ---------------------------------------------------------------------------------------------
 // the state machine: compute until the next exchange, exchange, continue
 // ---------------------------------------------------------------------------------------------
-static void set_allgather(DDState &D, const void *send, size_t bytes, DevBuf *recv)
-{
-  D.x.kind = 1;
-  D.x.send = send;
-  D.x.bytes = bytes;
-  D.x.recv = recv;
-}
-
-static void set_alltoallv(DDState &D, const void *send, size_t recbytes, const int *scount,
-                          const int *soff, DevBuf *recv)
-{
-  D.x.kind = 2;
-  D.x.send = send;
-  D.x.bytes = recbytes;
-  D.x.recv = recv;
-  for(int r = 0; r < D.nranks; r++)
-    {
-      D.x.scount[r] = scount[r];
-      D.x.soff[r] = soff[r];
-    }
-}
+#define set_allgather ghip_dd_set_allgather
+#define set_alltoallv ghip_dd_set_alltoallv
 
 // ---- gravity ------------------------------------------------------------------------------
 static int gravity_step(ghip_ctx *ctx)
@@ -1505,6 +1489,11 @@ extern "C" int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk
     D.dp = *reinterpret_cast<const ghip_dens_params *>(params);
   else if(op == DD_OP_HYDRO)
     D.hp = *reinterpret_cast<const ghip_hydro_params *>(params);
+  else if(op >= GHIP_DD_SINK_DENSITY && op <= GHIP_DD_BH_SWALLOW)
+    {
+      D.sink = *reinterpret_cast<const ghip_dd_sink_args *>(params);
+      GCHK(ghip_dd_sink_begin(ctx, op));
+    }
   else if(op == DD_OP_MIGRATE)
     {
       static_assert(sizeof(MigRec) == MIG_SLOTS * 8, "MigRec layout");
@@ -1536,6 +1525,8 @@ extern "C" int ghip_dd_step(ghip_ctx *ctx)
   if(D.x.kind != 0)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: run the pending exchange first");
   HIPCHK(hipSetDevice(ctx->device));
+  if(D.op >= GHIP_DD_SINK_DENSITY && D.op <= GHIP_DD_BH_SWALLOW)
+    return ghip_dd_sink_step(ctx);
   if(D.op == DD_OP_MIGRATE)
     return migrate_step(ctx);
   if(D.op == DD_OP_GRAVITY)
@@ -1600,7 +1591,8 @@ void ghip_dd_release(ghip_ctx *ctx)
                   &D.let_send, &D.let_recv, &D.src_x, &D.src_y, &D.src_z, &D.src_m, &D.src_aux,
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
                   &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,
-                  &D.mig_send, &D.mig_recv, &D.mig_scan, &D.gas_src};
+                  &D.mig_send, &D.mig_recv, &D.mig_scan, &D.gas_src, &D.sk_send, &D.sk_all, &D.sk_part,
+                  &D.sk_parts, &D.sk_work};
   for(DevBuf *b : bs)
     {
       if(b->p)

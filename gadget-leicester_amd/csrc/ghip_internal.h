@@ -98,6 +98,13 @@ struct DDXchg
   int rtotal = 0;
 };
 
+// state of the h iteration of a set of sinks (ghip_sink.hip)
+struct SinkIter
+{
+  std::vector<double> h, left, right, numngb, rho, entropy, gasvel;
+  std::vector<int> todo;
+};
+
 struct DDState
 {
   bool on = false;
@@ -138,9 +145,40 @@ struct DDState
   DevBuf mig_mask, mig_list, mig_send, mig_recv, mig_scan;
   DevBuf fshadow[GHIP_F_COUNT];
   int mig_out = 0, mig_in = 0;
+  // sinks on shards (ghip_sink.hip): every shard's sinks are made known to all, each shard
+  // evaluates all of them against its own particles, the partial sums are all-gathered
+  ghip_dd_sink_args sink;         // arguments of the operation in progress
+  DevBuf sk_send, sk_all;         // SinkRec[] of this shard / of all shards (rank order)
+  DevBuf sk_part, sk_parts;       // partial sums of this shard [k][nsink_total] / of all shards
+  DevBuf sk_work;                 // per pass: h[total] | slots[total]; swallow: BH masses [n] | victims [n]
+  int sk_total = 0, sk_off = 0, sk_iter = 0, sk_ncur = 0;
+  SinkIter sk_it;                 // h iteration state of ALL sinks (identical on all ranks)
   // traffic of the last operation (bytes this rank sent over links, excluding its own block)
   long long bytes_sent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// the pending exchange of a state-machine step (ghip_dd.hip, ghip_sink.hip)
+static inline void ghip_dd_set_allgather(DDState &D, const void *send, size_t bytes, DevBuf *recv)
+{
+  D.x.kind = 1;
+  D.x.send = send;
+  D.x.bytes = bytes;
+  D.x.recv = recv;
+}
+
+static inline void ghip_dd_set_alltoallv(DDState &D, const void *send, size_t recbytes,
+                                         const int *scount, const int *soff, DevBuf *recv)
+{
+  D.x.kind = 2;
+  D.x.send = send;
+  D.x.bytes = recbytes;
+  D.x.recv = recv;
+  for(int r = 0; r < D.nranks; r++)
+    {
+      D.x.scount[r] = scount[r];
+      D.x.soff[r] = soff[r];
+    }
+}
 
 struct ghip_ctx
 {

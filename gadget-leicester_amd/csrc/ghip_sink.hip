@@ -93,15 +93,25 @@ struct __attribute__((aligned(64))) SinkSphNode   // = SphNode of ghip_sph.hip
   int pad[2];
 };
 
-// out: [6][ns] planes: rho, weighted numngb, sum m w A, sum m w v[3]
+struct SinkRec   // what a pass needs of its sink (host fills it from the resident fields' values)
+{
+  double x, y, z, vx, vy, vz, mass, h, mdot, rho;
+  unsigned int id;
+  int timebin, index, pad;
+};
+
+// out: [6][ns] planes: rho, weighted numngb, sum m w A, sum m w v[3].  local_only (a multi-GPU shard,
+// whose gas tree also holds ghosts): candidates are this shard's own gas particles only -- the other
+// shards add theirs
 __global__ void __launch_bounds__(64)
-k_sink_density(int ns, const int *__restrict__ slot, const double *__restrict__ spos,
+k_sink_density(int ns, const int *__restrict__ slot, const SinkRec *__restrict__ recs,
                const double *__restrict__ sh, int nelem, const SinkSphNode *__restrict__ nodes,
                const double *__restrict__ gp, const int *__restrict__ perm,
-               const double *__restrict__ entropy, int ngas, SinkBox b, double *__restrict__ out)
+               const double *__restrict__ entropy, int ngas, int local_only, SinkBox b,
+               double *__restrict__ out)
 {
   const int a = slot[blockIdx.x], lane = threadIdx.x;
-  const double px = spos[3 * a], py = spos[3 * a + 1], pz = spos[3 * a + 2];
+  const double px = recs[a].x, py = recs[a].y, pz = recs[a].z;
   const double h = sh[a], h2 = h * h;
   double rho = 0, wn = 0, se = 0, g0 = 0, g1 = 0, g2 = 0;
   const double hinv = 1.0 / h, hinv3 = hinv * hinv * hinv;
@@ -146,8 +156,10 @@ k_sink_density(int ns, const int *__restrict__ slot, const double *__restrict__ 
           const double r2 = dx * dx + dy * dy + dz * dz;
           if(r2 < h2)
             {
-              const double wk = d_sink_kernel(sqrt(r2), h);
               const int j = perm[p];
+              if(local_only && j >= ngas)
+                continue;
+              const double wk = d_sink_kernel(sqrt(r2), h);
               rho += mass_j * wk;
               wn += NORM_COEFF * wk / hinv3;
               g0 += mass_j * wk * r8[4];
@@ -174,6 +186,136 @@ k_sink_density(int ns, const int *__restrict__ slot, const double *__restrict__ 
     }
 }
 
+// the sinks' own state from the resident fields (a few 8-byte reads each) + the per-sink inputs
+static int gather_sinks(ghip_ctx *ctx, int nsink, const int *idx, const unsigned int *id,
+                        const double *mdot, const double *rho, std::vector<SinkRec> &S)
+{
+  hipStream_t st = ctx->stream;
+  const size_t n = (size_t) ctx->n;
+  S.resize(nsink);
+  std::vector<int> tb(nsink > 0 ? nsink : 1);
+  for(int a = 0; a < nsink; a++)
+    {
+      const int i = idx[a];
+      if(i < 0 || i >= ctx->n)
+        return ghip_fail(ctx, GHIP_EINVAL, "sink index %d out of range", i);
+      const double *pos = P<double>(ctx->f[GHIP_F_POS]), *vel = P<double>(ctx->f[GHIP_F_VEL]);
+      HIPCHK(hipMemcpyAsync(&S[a].x, pos + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].y, pos + n + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].z, pos + 2 * n + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].vx, vel + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].vy, vel + n + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].vz, vel + 2 * n + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].mass, P<double>(ctx->f[GHIP_F_MASS]) + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&S[a].h, P<double>(ctx->f[GHIP_F_HSML]) + i, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&tb[a], P<int>(ctx->f[GHIP_F_TIMEBIN]) + i, 4, hipMemcpyDeviceToHost, st));
+      S[a].id = id ? id[a] : 0u;
+      S[a].mdot = mdot ? mdot[a] : 0.0;
+      S[a].rho = rho ? rho[a] : 1.0;
+      S[a].index = i;
+      S[a].pad = 0;
+    }
+  HIPCHK(hipStreamSynchronize(st));
+  for(int a = 0; a < nsink; a++)
+    S[a].timebin = tb[a];
+  return GHIP_OK;
+}
+
+// the h iteration of density() for non-gas targets (density.c:521-532, 548-551, 559-652 without the
+// Newton step, which needs SphP[].h.DhsmlDensityFactor: gas only, :613, 629), for sinks `todo[0..ncur)`
+// whose kernel sums of this pass are in sums[k * ns + a] (rho, numngb, entropy, gasvel[3]).  Returns the
+// number of sinks that need another pass (compacted to the front of `todo`).
+static int sink_iterate(const ghip_dens_params *p, double ngb_factor, int ns, const double *sums,
+                        int ncur, SinkIter &I)
+{
+  const double desnumngb = p->DesNumNgb * ngb_factor;
+  int left = 0;
+  for(int q = 0; q < ncur; q++)
+    {
+      const int a = I.todo[q];
+      const double rho = sums[a], wn = sums[(size_t) ns + a];
+      double h = I.h[a];
+      I.numngb[a] = wn;
+      I.rho[a] = rho;
+      for(int k = 0; k < 4; k++)
+        {
+          double v = sums[(size_t) (2 + k) * ns + a];
+          if(rho > 0)
+            v /= rho;
+          if(k == 0)
+            I.entropy[a] = v;
+          else
+            I.gasvel[3 * (size_t) a + k - 1] = v;
+        }
+      if(wn < (desnumngb - p->MaxNumNgbDeviation) ||
+         (wn > (desnumngb + p->MaxNumNgbDeviation) && h > (1.01 * p->MinGasHsml)))
+        {
+          if(I.left[a] > 0 && I.right[a] > 0 && (I.right[a] - I.left[a]) < 1.0e-3 * I.left[a])
+            continue;   // "this one should be ok"
+          if(wn < (desnumngb - p->MaxNumNgbDeviation))
+            I.left[a] = h > I.left[a] ? h : I.left[a];
+          else
+            {
+              if(I.right[a] != 0)
+                {
+                  if(h < I.right[a])
+                    I.right[a] = h;
+                }
+              else
+                I.right[a] = h;
+            }
+          if(I.right[a] > 0 && I.left[a] > 0)
+            h = pow(0.5 * (pow(I.left[a], 3) + pow(I.right[a], 3)), 1.0 / 3);
+          else
+            {
+              if(I.right[a] == 0 && I.left[a] > 0)
+                h *= 1.26;
+              if(I.right[a] > 0 && I.left[a] == 0)
+                h /= 1.26;
+            }
+          if(h < p->MinGasHsml)
+            h = p->MinGasHsml;
+          I.h[a] = h;
+          I.todo[left++] = a;
+        }
+    }
+  return left;
+}
+
+static void sink_iter_init(SinkIter &I, int ns)
+{
+  I.h.assign(ns, 0.0);
+  I.left.assign(ns, 0.0);
+  I.right.assign(ns, 0.0);
+  I.numngb.assign(ns, 0.0);
+  I.rho.assign(ns, 0.0);
+  I.entropy.assign(ns, 0.0);
+  I.gasvel.assign((size_t) 3 * ns, 0.0);
+  I.todo.resize(ns);
+  for(int a = 0; a < ns; a++)
+    I.todo[a] = a;
+}
+
+// one pass: kernel sums of the sinks todo[0..ncur) at their current h, into dout [6][ns]
+static int sink_density_pass(ghip_ctx *ctx, const ghip_dens_params *p, int ns, const SinkRec *drecs,
+                             double *dh, int *dslot, double *dout, const SinkIter &I, int ncur,
+                             int local_only)
+{
+  hipStream_t st = ctx->stream;
+  TreeDev &t = ctx->st;
+  SinkBox b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
+  HIPCHK(hipMemcpyAsync(dh, I.h.data(), (size_t) ns * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dslot, I.todo.data(), (size_t) ncur * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(dout, 0, (size_t) ns * 48, st));
+  if(t.nelem > 0)
+    k_sink_density<<<ncur, 64, 0, st>>>(ns, dslot, drecs, dh, t.nelem,
+                                        reinterpret_cast<const SinkSphNode *>(t.mq.p), P<double>(ctx->gp),
+                                        P<int>(t.perm), P<double>(ctx->f[GHIP_F_ENTROPY]), ctx->ngas,
+                                        local_only, b, dout);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
 extern "C" int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, double ngb_factor,
                                  int nsink, const int *sink_idx, double *hsml, double *numngb,
                                  double *bh_density, double *bh_entropy, double *bh_gasvel,
@@ -192,103 +334,29 @@ extern "C" int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, doubl
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_sink_density: call ghip_tree_build first");
   if(ctx->dd.on)
-    return ghip_fail(ctx, GHIP_EINVAL, "ghip_sink_density: not available on a multi-GPU shard");
-  for(int a = 0; a < nsink; a++)
-    if(sink_idx[a] < 0 || sink_idx[a] >= ctx->n)
-      return ghip_fail(ctx, GHIP_EINVAL, "ghip_sink_density: sink index %d out of range", sink_idx[a]);
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_sink_density: on a multi-GPU shard use GHIP_DD_SINK_DENSITY");
   hipStream_t st = ctx->stream;
-  const int n = ctx->n;
-  TreeDev &t = ctx->st;
-  // staging: pos[ns][3], h[ns], slot[ns] | out[6][ns]
-  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsink * (4 * 8 + 4 + 6 * 8) + 256));
-  double *dpos = P<double>(ctx->stage), *dh = dpos + 3 * (size_t) nsink, *dout = dh + nsink;
+  std::vector<SinkRec> S;
+  GCHK(gather_sinks(ctx, nsink, sink_idx, nullptr, nullptr, nullptr, S));
+  // staging: SinkRec[ns] | h[ns] | out[6][ns] | slot[ns]
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsink * (sizeof(SinkRec) + 8 + 48 + 4) + 256));
+  SinkRec *drecs = P<SinkRec>(ctx->stage);
+  double *dh = reinterpret_cast<double *>(drecs + nsink), *dout = dh + nsink;
   int *dslot = reinterpret_cast<int *>(dout + 6 * (size_t) nsink);
-  std::vector<double> hpos((size_t) nsink * 3), hh(nsink), hout((size_t) nsink * 6);
-  std::vector<double> Left(nsink, 0.0), Right(nsink, 0.0);
-  std::vector<int> todo(nsink);
-  {
-    // the sinks' coordinates from the resident field (3 planes of pitch n)
-    std::vector<double> tmp(3);
-    for(int a = 0; a < nsink; a++)
-      for(int k = 0; k < 3; k++)
-        HIPCHK(hipMemcpyAsync(&hpos[3 * (size_t) a + k],
-                              P<double>(ctx->f[GHIP_F_POS]) + (size_t) k * n + sink_idx[a], 8,
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-  }
-  HIPCHK(hipMemcpyAsync(dpos, hpos.data(), (size_t) nsink * 24, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(drecs, S.data(), (size_t) nsink * sizeof(SinkRec), hipMemcpyHostToDevice, st));
+  SinkIter I;
+  sink_iter_init(I, nsink);
   for(int a = 0; a < nsink; a++)
-    {
-      hh[a] = hsml[a];
-      todo[a] = a;
-    }
-  const double desnumngb = p->DesNumNgb * ngb_factor;   // density.c:548-551
+    I.h[a] = hsml[a];
+  std::vector<double> hout((size_t) nsink * 6);
   const int maxiter = p->MaxIter > 0 ? p->MaxIter : 150;
-  SinkBox b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   int ncur = nsink, iter = 0;
   while(ncur > 0)
     {
-      HIPCHK(hipMemcpyAsync(dh, hh.data(), (size_t) nsink * 8, hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemcpyAsync(dslot, todo.data(), (size_t) ncur * 4, hipMemcpyHostToDevice, st));
-      k_sink_density<<<ncur, 64, 0, st>>>(nsink, dslot, dpos, dh, t.nelem,
-                                          reinterpret_cast<const SinkSphNode *>(t.mq.p),
-                                          P<double>(ctx->gp), P<int>(t.perm),
-                                          P<double>(ctx->f[GHIP_F_ENTROPY]), ctx->ngas, b, dout);
-      HIPCHK(hipGetLastError());
+      GCHK(sink_density_pass(ctx, p, nsink, drecs, dh, dslot, dout, I, ncur, 0));
       HIPCHK(hipMemcpyAsync(hout.data(), dout, (size_t) nsink * 48, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      int left = 0;
-      for(int q = 0; q < ncur; q++)
-        {
-          const int a = todo[q];
-          const double rho = hout[a], wn = hout[(size_t) nsink + a];
-          double h = hh[a];
-          numngb[a] = wn;
-          bh_density[a] = rho;
-          for(int k = 0; k < 4; k++)   // density.c:521-532
-            {
-              double v = hout[(size_t) (2 + k) * nsink + a];
-              if(rho > 0)
-                v /= rho;
-              if(k == 0)
-                bh_entropy[a] = v;
-              else
-                bh_gasvel[3 * (size_t) a + k - 1] = v;
-            }
-          // density.c:559-652 without the Newton step (gas targets only, :613, 629)
-          if(wn < (desnumngb - p->MaxNumNgbDeviation) ||
-             (wn > (desnumngb + p->MaxNumNgbDeviation) && h > (1.01 * p->MinGasHsml)))
-            {
-              if(Left[a] > 0 && Right[a] > 0 && (Right[a] - Left[a]) < 1.0e-3 * Left[a])
-                continue;   // "this one should be ok"
-              if(wn < (desnumngb - p->MaxNumNgbDeviation))
-                Left[a] = h > Left[a] ? h : Left[a];
-              else
-                {
-                  if(Right[a] != 0)
-                    {
-                      if(h < Right[a])
-                        Right[a] = h;
-                    }
-                  else
-                    Right[a] = h;
-                }
-              if(Right[a] > 0 && Left[a] > 0)
-                h = pow(0.5 * (pow(Left[a], 3) + pow(Right[a], 3)), 1.0 / 3);
-              else
-                {
-                  if(Right[a] == 0 && Left[a] > 0)
-                    h *= 1.26;
-                  if(Right[a] > 0 && Left[a] == 0)
-                    h /= 1.26;
-                }
-              if(h < p->MinGasHsml)
-                h = p->MinGasHsml;
-              hh[a] = h;
-              todo[left++] = a;
-            }
-        }
-      ncur = left;
+      ncur = sink_iterate(p, ngb_factor, nsink, hout.data(), ncur, I);
       if(ncur > 0)
         {
           iter++;
@@ -299,9 +367,14 @@ extern "C" int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, doubl
     }
   for(int a = 0; a < nsink; a++)
     {
-      hsml[a] = hh[a];
+      hsml[a] = I.h[a];
+      numngb[a] = I.numngb[a];
+      bh_density[a] = I.rho[a];
+      bh_entropy[a] = I.entropy[a];
+      for(int k = 0; k < 3; k++)
+        bh_gasvel[3 * (size_t) a + k] = I.gasvel[3 * (size_t) a + k];
       // PPP[].Hsml of the sink on the device as well (blackhole_evaluate reads it)
-      HIPCHK(hipMemcpyAsync(P<double>(ctx->f[GHIP_F_HSML]) + sink_idx[a], &hh[a], 8,
+      HIPCHK(hipMemcpyAsync(P<double>(ctx->f[GHIP_F_HSML]) + sink_idx[a], &I.h[a], 8,
                             hipMemcpyHostToDevice, st));
     }
   HIPCHK(hipStreamSynchronize(st));
@@ -318,13 +391,6 @@ struct BhK
   SinkBox b;
   double ascale, dt_fac, smbh, inner, sinkb, softb, critdens, fbcoeff, unitmass;
   int dust, dust_only, acc_density;
-};
-
-struct SinkRec   // what a pass needs of its sink (host fills it from the resident fields' values)
-{
-  double x, y, z, vx, vy, vz, mass, h, mdot, rho;
-  unsigned int id;
-  int timebin, index, pad;
 };
 
 // walk the gravity tree around sink S; F(p, valid) is called by all 64 lanes with lane-own candidate p
@@ -562,41 +628,6 @@ static BhK bh_kparams(const ghip_bh_params *p)
   return K;
 }
 
-// the sinks' own state from the resident fields (a few 8-byte reads each) + the per-sink inputs
-static int gather_sinks(ghip_ctx *ctx, int nsink, const int *idx, const unsigned int *id,
-                        const double *mdot, const double *rho, std::vector<SinkRec> &S)
-{
-  hipStream_t st = ctx->stream;
-  const size_t n = (size_t) ctx->n;
-  S.resize(nsink);
-  std::vector<int> tb(nsink);
-  for(int a = 0; a < nsink; a++)
-    {
-      const int i = idx[a];
-      if(i < 0 || i >= ctx->n)
-        return ghip_fail(ctx, GHIP_EINVAL, "sink index %d out of range", i);
-      const double *pos = P<double>(ctx->f[GHIP_F_POS]), *vel = P<double>(ctx->f[GHIP_F_VEL]);
-      HIPCHK(hipMemcpyAsync(&S[a].x, pos + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].y, pos + n + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].z, pos + 2 * n + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].vx, vel + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].vy, vel + n + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].vz, vel + 2 * n + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].mass, P<double>(ctx->f[GHIP_F_MASS]) + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&S[a].h, P<double>(ctx->f[GHIP_F_HSML]) + i, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&tb[a], P<int>(ctx->f[GHIP_F_TIMEBIN]) + i, 4, hipMemcpyDeviceToHost, st));
-      S[a].id = id[a];
-      S[a].mdot = mdot ? mdot[a] : 0.0;
-      S[a].rho = rho ? rho[a] : 1.0;
-      S[a].index = i;
-      S[a].pad = 0;
-    }
-  HIPCHK(hipStreamSynchronize(st));
-  for(int a = 0; a < nsink; a++)
-    S[a].timebin = tb[a];
-  return GHIP_OK;
-}
-
 static int check_bh_call(ghip_ctx *ctx, const ghip_bh_params *p, int nsink, const void *idx,
                          const void *id, const char *who)
 {
@@ -827,4 +858,238 @@ extern "C" int ghip_cooling_and_starformation(ghip_ctx *ctx, double Timebase_int
     HIPCHK(hipMemcpyAsync(flag_sink_host, ctx->dflags.p, (size_t) ng * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sink passes on a multi-GPU shard (GHIP_DD_SINK_DENSITY / _BH_EVALUATE / _BH_SWALLOW)
+//
+// The reference exports the few sink targets to the tasks whose domains their search spheres touch
+// (density.c:384-470, blackhole.c:310-600) and adds the partial results back on the home task.
+// Here every shard learns ALL sinks (96-byte records, an all-to-all-v that includes the sender),
+// runs each pass for all of them over ITS OWN particles, and the per-sink partial sums are
+// all-gathered and added in rank order on every shard: the h iteration then takes the same decisions
+// everywhere without another exchange, and a victim, local to exactly one shard, sees every claim.
+// ---------------------------------------------------------------------------------------------
+int ghip_dd_sink_begin(ghip_ctx *ctx, int op)
+{
+  GHIP_JOIN(ctx);
+  DDState &D = ctx->dd;
+  const ghip_dd_sink_args &A = D.sink;
+  if(A.nsink < 0 || (A.nsink > 0 && !A.sink_idx))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd sinks: bad arguments");
+  if(op == GHIP_DD_SINK_DENSITY)
+    {
+      if(!A.dens || (A.nsink > 0 && (!A.hsml || !A.numngb || !A.bh_density || !A.bh_entropy || !A.bh_gasvel)))
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd sink density: bad arguments");
+      if(!ctx->st.built)
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd sink density: run GHIP_DD_DENSITY of this step first");
+    }
+  else
+    {
+      if(!A.bh || (A.nsink > 0 && !A.sink_id))
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd black holes: bad arguments");
+      if(op == GHIP_DD_BH_EVALUATE && A.nsink > 0 && (!A.bh_mdot || !A.bh_density_in))
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd black holes: bad arguments");
+      if(op == GHIP_DD_BH_SWALLOW && A.nsink > 0 &&
+         (!A.sink_bh_mass || !A.acc_mass || !A.acc_bhmass || !A.acc_dustmass || !A.acc_momentum))
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd black holes: bad arguments");
+      if(!ctx->gt.built)
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd black holes: run GHIP_DD_GRAVITY of this step first");
+    }
+  return GHIP_OK;
+}
+
+// one density pass of the sinks still iterating, over this shard's own gas; the partial sums go
+// to everybody
+static int dd_sink_density_pass(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  const int ns = D.sk_total;
+  GCHK(ghip_ensure(ctx, D.sk_part, (size_t) ns * 48));
+  GCHK(ghip_ensure(ctx, D.sk_work, (size_t) ns * 12 + 64));
+  double *dh = P<double>(D.sk_work);
+  int *dslot = reinterpret_cast<int *>(dh + ns);
+  GCHK(sink_density_pass(ctx, D.sink.dens, ns, P<SinkRec>(D.sk_all), dh, dslot, P<double>(D.sk_part),
+                         D.sk_it, D.sk_ncur, 1));
+  ghip_dd_set_allgather(D, D.sk_part.p, (size_t) ns * 48, &D.sk_parts);
+  return 1;
+}
+
+// rank-ordered sum of the all-gathered partial planes [nranks][k][ns]
+static int dd_sink_sum_parts(ghip_ctx *ctx, int k, std::vector<double> &parts, std::vector<double> &sums)
+{
+  DDState &D = ctx->dd;
+  const size_t per = (size_t) k * D.sk_total;
+  parts.resize(per * D.nranks);
+  sums.assign(per, 0.0);
+  HIPCHK(hipMemcpyAsync(parts.data(), D.sk_parts.p, per * D.nranks * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for(int r = 0; r < D.nranks; r++)
+    for(size_t q = 0; q < per; q++)
+      sums[q] += parts[(size_t) r * per + q];
+  return GHIP_OK;
+}
+
+int ghip_dd_sink_step(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  const ghip_dd_sink_args &A = D.sink;
+  hipStream_t st = ctx->stream;
+  const int op = D.op, nloc = A.nsink;
+  if(D.phase == 0)
+    {
+      // this shard's sinks to every shard (itself included: the receive buffer is the rank-ordered
+      // list of all sinks)
+      std::vector<SinkRec> S;
+      GCHK(gather_sinks(ctx, nloc, A.sink_idx, A.sink_id, op == GHIP_DD_BH_EVALUATE ? A.bh_mdot : nullptr,
+                        op == GHIP_DD_BH_EVALUATE ? A.bh_density_in : nullptr, S));
+      if(op == GHIP_DD_SINK_DENSITY)
+        for(int a = 0; a < nloc; a++)
+          S[a].h = A.hsml[a];
+      GCHK(ghip_ensure(ctx, D.sk_send, (size_t) (nloc > 0 ? nloc : 1) * sizeof(SinkRec)));
+      if(nloc > 0)
+        HIPCHK(hipMemcpyAsync(D.sk_send.p, S.data(), (size_t) nloc * sizeof(SinkRec), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));   // S goes out of scope
+      int scount[GHIP_MAXRANKS], soff[GHIP_MAXRANKS];
+      for(int r = 0; r < D.nranks; r++)
+        {
+          scount[r] = nloc;
+          soff[r] = 0;
+        }
+      ghip_dd_set_alltoallv(D, D.sk_send.p, sizeof(SinkRec), scount, soff, &D.sk_all);
+      D.phase = 1;
+      return 1;
+    }
+  if(D.phase == 1)
+    {
+      D.sk_total = D.x.rtotal;
+      D.sk_off = D.x.roff[D.rank];
+      const int ns = D.sk_total;
+      if(D.x.rcount[D.rank] != nloc)
+        return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd sinks: the exchange lost this shard's own records");
+      if(op == GHIP_DD_BH_SWALLOW && A.counts)
+        A.counts[0] = A.counts[1] = A.counts[2] = 0;
+      if(ns == 0)
+        {
+          D.op = 0;
+          return 0;
+        }
+      if(op == GHIP_DD_SINK_DENSITY)
+        {
+          std::vector<SinkRec> all(ns);
+          HIPCHK(hipMemcpyAsync(all.data(), D.sk_all.p, (size_t) ns * sizeof(SinkRec), hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          sink_iter_init(D.sk_it, ns);
+          for(int a = 0; a < ns; a++)
+            D.sk_it.h[a] = all[a].h;
+          D.sk_ncur = ns;
+          D.sk_iter = 0;
+          D.phase = 2;
+          return dd_sink_density_pass(ctx);
+        }
+      GCHK(sink_buffers(ctx));
+      TreeDev &t = ctx->gt;
+      const size_t n = (size_t) ctx->n;
+      if(op == GHIP_DD_BH_EVALUATE)
+        {
+          k_bh_evaluate<<<ns, 64, 0, st>>>(ns, P<SinkRec>(D.sk_all), t.nelem, P<int4>(t.lk), P<double4>(t.cl),
+                                           P<double>(ctx->sx), P<double>(ctx->sy), P<double>(ctx->sz),
+                                           P<int>(t.perm), ctx->n, ctx->ngas, P<int>(ctx->f[GHIP_F_TYPE]),
+                                           P<double>(ctx->f[GHIP_F_MASS]), P<double>(ctx->f[GHIP_F_VEL]),
+                                           P<double>(ctx->f[GHIP_F_DENSITY]), bh_kparams(A.bh),
+                                           P<unsigned int>(ctx->bh_swallow), P<double>(ctx->bh_injected));
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipStreamSynchronize(st));
+          D.op = 0;
+          return 0;
+        }
+      // GHIP_DD_BH_SWALLOW: BH masses of this shard's sinks by particle, then every sink's sweep
+      GCHK(ghip_ensure(ctx, D.sk_part, (size_t) ns * 72));
+      GCHK(ghip_ensure(ctx, D.sk_work, (n > 0 ? n : 1) * 12 + (size_t) (nloc > 0 ? nloc : 1) * 8 + 64));
+      double *dpbh = P<double>(D.sk_work);
+      int *dvict = reinterpret_cast<int *>(dpbh + n);
+      double *dbh = reinterpret_cast<double *>(reinterpret_cast<char *>(D.sk_work.p) + ((n * 12 + 63) & ~(size_t) 63));
+      HIPCHK(hipMemsetAsync(dpbh, 0, n * 12, st));
+      if(nloc > 0)
+        {
+          HIPCHK(hipMemcpyAsync(dbh, A.sink_bh_mass, (size_t) nloc * 8, hipMemcpyHostToDevice, st));
+          k_bh_scatter<<<cdiv(nloc, 64), 64, 0, st>>>(nloc, P<SinkRec>(D.sk_send), dbh, dpbh);
+        }
+      k_bh_swallow<<<ns, 64, 0, st>>>(ns, P<SinkRec>(D.sk_all), t.nelem, P<int4>(t.lk), P<double4>(t.cl),
+                                      P<double>(ctx->sx), P<double>(ctx->sy), P<double>(ctx->sz),
+                                      P<int>(t.perm), ctx->n, P<int>(ctx->f[GHIP_F_TYPE]),
+                                      P<double>(ctx->f[GHIP_F_MASS]), P<double>(ctx->f[GHIP_F_VEL]), dpbh,
+                                      bh_kparams(A.bh), P<unsigned int>(ctx->bh_swallow), dvict,
+                                      P<double>(D.sk_part));
+      if(n > 0)
+        k_bh_zero_victims<<<cdiv((long long) n, 256), 256, 0, st>>>((int) n, dvict,
+                                                                   P<double>(ctx->f[GHIP_F_MASS]));
+      HIPCHK(hipGetLastError());
+      ghip_dd_set_allgather(D, D.sk_part.p, (size_t) ns * 72, &D.sk_parts);
+      D.phase = 2;
+      return 1;
+    }
+  if(D.phase == 2 && op == GHIP_DD_SINK_DENSITY)
+    {
+      const int ns = D.sk_total;
+      std::vector<double> parts, sums;
+      GCHK(dd_sink_sum_parts(ctx, 6, parts, sums));
+      D.sk_ncur = sink_iterate(A.dens, A.ngb_factor, ns, sums.data(), D.sk_ncur, D.sk_it);
+      if(D.sk_ncur > 0)
+        {
+          const int maxiter = A.dens->MaxIter > 0 ? A.dens->MaxIter : 150;
+          if(++D.sk_iter > maxiter)
+            return ghip_fail(ctx, GHIP_ENOCONV, "sink density: %d sinks not converged after %d "
+                             "h-iterations (reference: endrun(1155))", D.sk_ncur, maxiter);
+          return dd_sink_density_pass(ctx);
+        }
+      const SinkIter &I = D.sk_it;
+      for(int a = 0; a < nloc; a++)
+        {
+          const int g = D.sk_off + a;
+          A.hsml[a] = I.h[g];
+          A.numngb[a] = I.numngb[g];
+          A.bh_density[a] = I.rho[g];
+          A.bh_entropy[a] = I.entropy[g];
+          for(int k = 0; k < 3; k++)
+            A.bh_gasvel[3 * (size_t) a + k] = I.gasvel[3 * (size_t) g + k];
+          HIPCHK(hipMemcpyAsync(P<double>(ctx->f[GHIP_F_HSML]) + A.sink_idx[a], &I.h[g], 8,
+                                hipMemcpyHostToDevice, st));
+        }
+      HIPCHK(hipStreamSynchronize(st));
+      D.op = 0;
+      return 0;
+    }
+  if(D.phase == 2 && op == GHIP_DD_BH_SWALLOW)
+    {
+      const int ns = D.sk_total;
+      const size_t n = (size_t) ctx->n;
+      std::vector<double> parts, sums;
+      GCHK(dd_sink_sum_parts(ctx, 9, parts, sums));
+      const int *dvict = reinterpret_cast<const int *>(P<double>(D.sk_work) + n);
+      std::vector<int> vict(nloc > 0 ? nloc : 1);
+      for(int a = 0; a < nloc; a++)
+        HIPCHK(hipMemcpyAsync(&vict[a], dvict + A.sink_idx[a], 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for(int a = 0; a < nloc; a++)
+        {
+          const int g = D.sk_off + a;
+          A.acc_mass[a] = sums[g];
+          A.acc_bhmass[a] = sums[(size_t) ns + g];
+          A.acc_dustmass[a] = sums[2 * (size_t) ns + g];
+          for(int k = 0; k < 3; k++)
+            A.acc_momentum[3 * (size_t) a + k] = sums[(size_t) (3 + k) * ns + g];
+          if(vict[a])
+            A.sink_bh_mass[a] = 0;   // P[j].BH_Mass = 0 of a swallowed sink (blackhole.c:1274)
+        }
+      if(A.counts)   // what THIS shard's particles lost: the planes of this rank's block
+        for(int k = 0; k < 3; k++)
+          for(int g = 0; g < ns; g++)
+            A.counts[k] += (long long) (parts[(size_t) D.rank * 9 * ns + (size_t) (6 + k) * ns + g] + 0.5);
+      ctx->gt.built = false;   // masses changed: the trees' moments are stale
+      ctx->st.built = false;
+      D.op = 0;
+      return 0;
+    }
+  return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: the sink passes have no phase %d", D.phase);
 }

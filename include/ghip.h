@@ -432,6 +432,34 @@ int ghip_cooling_and_starformation(ghip_ctx *ctx, double Timebase_interval,
                                    double CritPhysDensity_code, double MinEgySpec,
                                    double u_to_temp_fac, int *flag_sink_host);
 
+/* The sink passes on a multi-GPU shard (GHIP_DD_SINK_DENSITY / _BH_EVALUATE / _BH_SWALLOW through
+ * ghip_dd_begin / ghip_dd_run): the sinks of every shard are made known to all shards (a few hundred
+ * 96-byte records), each shard evaluates ALL sinks against ITS OWN particles, and the partial sums
+ * (density: 6 doubles per sink and h iteration; swallow: 9) are all-gathered and added in rank order
+ * -- the reference's export of the few sink targets (blackhole.c:310-600) instead of an import of
+ * their neighbourhoods.  A victim is local to exactly one shard, which sees every sink's claim, so
+ * the marks equal the single-GPU ones.  Arrays of this struct describe the sinks resident on THIS
+ * shard; members an operation does not use may be NULL. */
+typedef struct
+{
+  const ghip_dens_params *dens;   /* SINK_DENSITY */
+  double ngb_factor;              /* All.BlackHoleNgbFactor */
+  const ghip_bh_params *bh;       /* BH_EVALUATE, BH_SWALLOW */
+  int nsink;                      /* sinks resident on this shard */
+  const int *sink_idx;            /* their local particle indices */
+  const unsigned int *sink_id;    /* P[].ID */
+  double *hsml;                   /* [nsink] SINK_DENSITY in/out */
+  double *numngb, *bh_density, *bh_entropy, *bh_gasvel;   /* SINK_DENSITY out ([nsink], gasvel [nsink][3]) */
+  const double *bh_mdot;          /* BH_EVALUATE in */
+  const double *bh_density_in;    /* BH_EVALUATE in */
+  double *sink_bh_mass;           /* BH_SWALLOW in/out */
+  double *acc_mass, *acc_bhmass, *acc_dustmass, *acc_momentum;   /* BH_SWALLOW out */
+  long long *counts;              /* BH_SWALLOW out [3]: gas / sinks / dust swallowed ON THIS SHARD */
+} ghip_dd_sink_args;
+#define GHIP_DD_SINK_DENSITY 5   /* needs GHIP_DD_DENSITY of this step (the shard's gas tree) */
+#define GHIP_DD_BH_EVALUATE 6    /* needs GHIP_DD_GRAVITY of this step (the shard's gravity tree) */
+#define GHIP_DD_BH_SWALLOW 7
+
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
                     double DomainLen, const double ForceSoftening[6]);

@@ -228,6 +228,16 @@ class ShardSet:
     def each(self, fn):
         return [fn(fp) for fp in self.fp]
 
+    def locate(self, glob):
+        """per shard: (local indices of the particles `glob` it holds, their positions in `glob`)"""
+        glob = np.asarray(glob, np.int64)
+        out = []
+        for g in self.gid:
+            where = {int(v): i for i, v in enumerate(g)}
+            pos = [k for k, v in enumerate(glob) if int(v) in where]
+            out.append((np.array([where[int(glob[k])] for k in pos], np.int32), np.array(pos, np.int64)))
+        return out
+
     def close(self):
         for fp in self.fp:
             fp.close()
