@@ -231,11 +231,15 @@ class ShardSet:
     def locate(self, glob):
         """per shard: (local indices of the particles `glob` it holds, their positions in `glob`)"""
         glob = np.asarray(glob, np.int64)
+        shard = np.full(self.pr.n, -1, np.int32)
+        local = np.zeros(self.pr.n, np.int32)
+        for r, g in enumerate(self.gid):
+            shard[g] = r
+            local[g] = np.arange(len(g), dtype=np.int32)
         out = []
-        for g in self.gid:
-            where = {int(v): i for i, v in enumerate(g)}
-            pos = [k for k, v in enumerate(glob) if int(v) in where]
-            out.append((np.array([where[int(glob[k])] for k in pos], np.int32), np.array(pos, np.int64)))
+        for r in range(self.P):
+            pos = np.where(shard[glob] == r)[0]
+            out.append((local[glob[pos]].astype(np.int32), pos.astype(np.int64)))
         return out
 
     def close(self):

@@ -8,7 +8,7 @@ counts must be exact and the sums agree to summation order."""
 import numpy as np
 import pytest
 
-from common import O, Problem, ShardSet, bindings, relerr
+from common import O, Problem, ShardSet, SinkProblem, bindings, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -145,6 +145,104 @@ def test_config_c4_128cubed_as_eight_logical_shards():
                   (r, sizes[r], i["let_imported"], i["bytes_gravity"] / 1e6, i["ghosts_imported"],
                    i["bytes_density"] / 1e6, i["grav_elements"]))
         assert all(0 < i["let_imported"] < 0.6 * n for i in info)
+    finally:
+        S.close()
+
+
+def test_config_c5_256cubed_with_sinks_as_eight_logical_shards():
+    """c5 (256^3 DM + 256^3 gas = 33.5 million particles with 300 sinks and 3000 dust grains, 8 GPUs):
+    the whole workload as 8 logical shards on one GPU.  One force step -- Newtonian + Ewald walks under
+    the relative criterion, density, hydro -- and the sink passes of blackhole.c on the shards, against
+    the oracle's single global tree: gravity on a sample of targets from all shards (interaction counts
+    exact), SPH through the neighbour window and momentum balance, the 300 sinks' h, marks and
+    swallow counts against the oracle's global passes (marks and counts exact)."""
+    B = bindings()
+    sp = SinkProblem(ng=256, periodic=1, nsink=300, ndust=3000)
+    pr = sp.pr
+    n, ng = pr.n, pr.ngas
+    assert n == 2 * 256 ** 3
+    rng = np.random.default_rng(12)
+    old = np.full(n, 2.0)
+    S = ShardSet(pr, 8, fields={"oldacc": old})
+    try:
+        sizes = [len(g) for g in S.gid]
+        assert sum(sizes) == n and max(sizes) < 1.3 * n / 8
+        S.run.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+        S.each(lambda fp: fp.dd_set_ghost_margin(1.6))
+        S.run.density(pr.g_dens())
+        S.each(lambda fp: fp.update_hmax())
+        S.run.hydro(pr.g_hydro())
+        acc, cost = S.get_field(B.F_GRAVACCEL), S.get_field(B.F_GRAVCOST)
+        st = S.each(lambda fp: fp.stats())
+        info = S.each(lambda fp: fp.dd_info())
+        assert int(cost.astype(np.int64).sum()) == sum(s["grav_interactions"] + s["ewald_interactions"]
+                                                      for s in st)
+        nn = S.get_field(B.F_NUMNGB)
+        assert np.all(np.abs(nn - pr.des_ngb) <= pr.max_dev + 1e-9)
+        ha = S.get_field(B.F_HYDROACCEL)
+        mg = pr.ic["mass"][:ng]
+        assert np.abs((mg[:, None] * ha).sum(axis=0)).max() < 1e-10 * np.abs(mg[:, None] * ha).sum()
+        sample = np.sort(rng.choice(n, 512, replace=False)).astype(np.int32)
+        assert len(np.unique(S.owner[sample])) == 8
+        T = pr.oracle_tree()
+        oacc, ocost = T.gravity(pr.o_grav(0.0), sample, old)
+        T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
+        assert np.array_equal(cost[sample], ocost)
+        assert relerr(acc[sample], oacc) < TOL
+        # ---- the sinks, spread over the shards ----
+        where = S.locate(sp.sinks)
+        assert sum(len(w[0]) for w in where) == 300 and sum(len(w[0]) > 0 for w in where) >= 4
+        hs = S.get_field(B.F_HSML)
+        hs[sp.sinks] = sp.hsml[sp.sinks]
+        gas_density = S.get_field(B.F_DENSITY)
+        par = dict(accretion_of_dust_only=0, CritDensity=float(np.median(gas_density)))
+        T.hsml = hs
+        od = O.sink_density(T, pr.o_dens(), 1.5, sp.sinks, pr.velpred, pr.entropy, hs)
+        gd, gp = pr.g_dens(), sp.params(B.BhParams, **par)
+
+        def run(op, make):
+            built = [make(r) for r in range(8)]
+            S.run.run(op, [b[0] for b in built])
+            return [b[1] for b in built]
+
+        res = run(B.DD_SINK_DENSITY, lambda r: B.dd_sink_args(
+            where[r][0], dens=gd, ngb_factor=1.5, hsml=hs[sp.sinks][where[r][1]]))
+        gh, grho = np.zeros(300), np.zeros(300)
+        for (loc, pos), a in zip(where, res):
+            gh[pos], grho[pos] = a["hsml"], a["density"]
+        assert relerr(gh, od["hsml"][sp.sinks]) < 1e-13
+        assert relerr(grho, od["density"]) < TOL
+        S.each(lambda fp: fp.sink_reset())
+        osw, oinj = O.blackhole_evaluate(T, sp.params(O.BhParams, **par), sp.sinks, sp.ids, od["hsml"],
+                                         pr.timebin, sp.mdot, od["density"], gas_density,
+                                         np.zeros(n, np.uint32), np.zeros(ng))
+        run(B.DD_BH_EVALUATE, lambda r: B.dd_sink_args(
+            where[r][0], sink_ids=sp.ids[sp.sinks][where[r][1]], bh=gp, mdot=sp.mdot[where[r][1]],
+            bh_density=grho[where[r][1]]))
+        gsw, ginj = np.zeros(n, np.uint32), np.zeros(ng)
+        for r, fp in enumerate(S.fp):
+            sw, inj = fp.sink_marks()
+            gsw[S.gid[r]] = sw
+            ginj[S.gid[r][:S.ngas[r]]] = inj
+        assert np.array_equal(gsw, osw) and (osw > 0).sum() > 300
+        assert np.abs(ginj - oinj).max() <= 1e-11 * np.abs(oinj).max()
+        oo = O.blackhole_swallow(T, sp.params(O.BhParams, **par), sp.sinks, sp.ids, od["hsml"], osw,
+                                 sp.bh_mass)
+        res = run(B.DD_BH_SWALLOW, lambda r: B.dd_sink_args(
+            where[r][0], sink_ids=sp.ids[sp.sinks][where[r][1]], bh=gp,
+            sink_bh_mass=sp.bh_mass[sp.sinks][where[r][1]]))
+        counts, gm = np.zeros(3, np.int64), np.zeros(300)
+        for (loc, pos), a in zip(where, res):
+            counts += a["counts"]
+            gm[pos] = a["acc_mass"]
+        assert np.array_equal(counts, oo["counts"])
+        assert np.abs(gm - oo["acc_mass"]).max() <= 1e-13 * oo["acc_mass"].max()
+        assert np.array_equal(S.get_field(B.F_MASS), T.mass)
+        for r, i in enumerate(info):
+            print("shard %d: %d particles (%d sinks), %d tree elements imported (%.1f MB sent), %d "
+                  "ghosts imported (%.1f MB sent), merged tree %d elements" %
+                  (r, sizes[r], len(where[r][0]), i["let_imported"], i["bytes_gravity"] / 1e6,
+                   i["ghosts_imported"], i["bytes_density"] / 1e6, i["grav_elements"]))
     finally:
         S.close()
 
