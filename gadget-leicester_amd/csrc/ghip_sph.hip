@@ -208,12 +208,57 @@ __device__ __forceinline__ void d_load_sphnode(const SphNode *__restrict__ base,
 #endif
 
 
-// density_evaluate (density.c:711-1029, mode 0) for a bucket of 64 curve-consecutive targets.
-// One wavefront per workgroup.  Node records come through the scalar path; when a node with
-// <= 64 gas particles overlaps any lane's search sphere its particle records (contiguous in
-// gas-tree order) are fetched with ONE coalesced vector load -- lane l loads candidate l --
-// into LDS, and every lane then reads candidate j as a broadcast ds_read: one memory latency per
-// 64 candidates instead of one per candidate.  Each lane applies the exact test r2 < h_i^2.
+// up to CS staged candidates of one batch at a time: candidate slot c takes the c-th lowest set bit
+// of `live` (wave-uniform, scalar unit); a lane of slot cs reads ITS candidate from LDS.  Returns the
+// lane's candidate index or -1.
+template <int CS>
+__device__ __forceinline__ int d_next_candidates(unsigned long long &live, int cs)
+{
+  int mine = -1;
+#pragma unroll
+  for(int c = 0; c < CS; c++)
+    {
+      const int j = live ? __builtin_ctzll(live) : -1;
+      live &= live - 1;   // (0 & anything = 0)
+      if(CS == 1 || cs == c)
+        mine = j;
+    }
+  return mine;
+}
+
+// sum over the candidate slots of a target (lanes t, t + TG, t + 2 TG, ...): fixed order
+template <int TG>
+__device__ __forceinline__ double d_slot_sum(double v)
+{
+#pragma unroll
+  for(int off = TG; off < 64; off <<= 1)
+    v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int TG>
+__device__ __forceinline__ double d_slot_max(double v)
+{
+#pragma unroll
+  for(int off = TG; off < 64; off <<= 1)
+    {
+      const double o = __shfl_xor(v, off, 64);
+      v = o > v ? o : v;
+    }
+  return v;
+}
+
+// density_evaluate (density.c:711-1029, mode 0) for a bucket of TG curve-consecutive targets.
+// One wavefront per workgroup = TG targets x CS = 64/TG candidate slots: lane l works for target
+// l % TG on the candidates of slot l / TG.  Node records come through the scalar path; when a node
+// with <= SPH_LEAF gas particles overlaps any target's search sphere its particle records
+// (contiguous in gas-tree order) are fetched 64 at a time with ONE coalesced vector load -- lane l
+// loads candidate l -- into LDS and culled against the bucket's bounds; the survivors are then taken
+// CS at a time, slot c testing survivor c against its TG targets with the exact test r2 < h_i^2
+// (a per-lane ds_read, broadcast within a slot).  A smaller bucket has a tighter bound (fewer
+// survivors per target) and CS survivors share one pass of the pair arithmetic: at TG = 16 a
+// candidate test accepts 4 x as often as with 64 targets per wavefront.  The slots' partial sums are
+// added in fixed order at the end.
+template <int TG>
 __global__ void __launch_bounds__(64)
 k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp, int nt,
           int nsub, const int *__restrict__ tgt, const double *__restrict__ hcur, BoxK b,
@@ -221,12 +266,14 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
           double *__restrict__ pdiv, double *__restrict__ prot,
           unsigned long long *__restrict__ counter)
 {
+  constexpr int CS = 64 / TG;
   __shared__ double4 sh[SPH_STAGE][2];
   const int lane = threadIdx.x;
+  const int tl = lane & (TG - 1), cs = lane / TG;
   const int bucket = blockIdx.x / nsub;
   const int sub = blockIdx.x - bucket * nsub;   // this wavefront takes every nsub-th batch
   int batch = 0;
-  const int ti = bucket * 64 + lane;
+  const int ti = bucket * TG + tl;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
   double px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0, h = 1;
@@ -256,8 +303,8 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
       if(pidx >= 0)
         {
           if((batch++ % nsub) == sub)
-            d_density_pair(gp + (size_t) 8 * pidx, valid, px, py, pz, vx, vy, vz, h2, hinv, hinv3,
-                           hinv4, b, A);
+            d_density_pair(gp + (size_t) 8 * pidx, valid && cs == 0, px, py, pz, vx, vy, vz, h2, hinv,
+                           hinv3, hinv4, b, A);
           e = e + 1;
         }
       else
@@ -286,10 +333,10 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
                         __syncthreads();
                         while(live)
                           {
-                            const int j = __builtin_ctzll(live);
-                            live &= live - 1;
-                            d_density_pair(reinterpret_cast<const double *>(&sh[j][0]), valid, px,
-                                           py, pz, vx, vy, vz, h2, hinv, hinv3, hinv4, b, A);
+                            const int j = d_next_candidates<CS>(live, cs);
+                            d_density_pair(reinterpret_cast<const double *>(&sh[j < 0 ? 0 : j][0]),
+                                           valid && j >= 0, px, py, pz, vx, vy, vz, h2, hinv, hinv3,
+                                           hinv4, b, A);
                           }
                       }
                   e = skip;
@@ -301,17 +348,20 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
             e = skip;
         }
     }
-  if(valid)
+  const double rho = d_slot_sum<TG>(A.rho), wnum = d_slot_sum<TG>(A.wnum), dh = d_slot_sum<TG>(A.dhsml);
+  const double dv = d_slot_sum<TG>(A.divv), rx = d_slot_sum<TG>(A.rx), ry = d_slot_sum<TG>(A.ry);
+  const double rz = d_slot_sum<TG>(A.rz);
+  if(valid && cs == 0)
     {
       const size_t o = (size_t) sub * nt + ti;
       const size_t plane = (size_t) nsub * nt;
-      prho[o] = A.rho;
-      pnum[o] = A.wnum;
-      pdh[o] = A.dhsml;
-      pdiv[o] = A.divv;
-      prot[o] = A.rx;
-      prot[plane + o] = A.ry;
-      prot[2 * plane + o] = A.rz;
+      prho[o] = rho;
+      pnum[o] = wnum;
+      pdh[o] = dh;
+      pdiv[o] = dv;
+      prot[o] = rx;
+      prot[plane + o] = ry;
+      prot[2 * plane + o] = rz;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.nn);
   if(lane == 0 && tot)
@@ -524,6 +574,34 @@ static int ghip_sph_target_waves()
   return v;
 }
 
+// targets per wavefront of the SPH kernels (the other 64/TG lanes of a target are candidate slots)
+static int ghip_sph_tg()
+{
+  static int v = -1;
+  if(v < 0)
+    {
+      v = 16;
+      const char *e = getenv("GHIP_SPH_TG");
+      if(e && (atoi(e) == 64 || atoi(e) == 32 || atoi(e) == 16 || atoi(e) == 8))
+        v = atoi(e);
+    }
+  return v;
+}
+
+#define SPH_LAUNCH(KERNEL, TGV, GRID, ST, ...)                                   \
+  do                                                                             \
+    {                                                                            \
+      if((TGV) == 64)                                                            \
+        KERNEL<64><<<(GRID), 64, 0, (ST)>>>(__VA_ARGS__);                        \
+      else if((TGV) == 32)                                                       \
+        KERNEL<32><<<(GRID), 64, 0, (ST)>>>(__VA_ARGS__);                        \
+      else if((TGV) == 16)                                                       \
+        KERNEL<16><<<(GRID), 64, 0, (ST)>>>(__VA_ARGS__);                        \
+      else                                                                       \
+        KERNEL<8><<<(GRID), 64, 0, (ST)>>>(__VA_ARGS__);                         \
+    }                                                                            \
+  while(0)
+
 static void shard_slice(const ghip_ctx *ctx, int nt, int *lo, int *cnt)
 {
   int per;
@@ -663,13 +741,13 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
     {
       // wavefronts per bucket: enough of them to occupy the chip when the target list is short
       // (late h-iterations, one rank's share of a multi-GPU run); each takes every nsub-th batch
-      const int nbk = (ncur + 63) / 64;
+      const int tgw = ghip_sph_tg();
+      const int nbk = (ncur + tgw - 1) / tgw;
       int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
       nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
-      k_density<<<nbk * nsub, 64, 0, st>>>(
-        t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur, nsub, cur, hcur, b, P<double>(ctx->drho),
-        P<double>(ctx->dnumngb), P<double>(ctx->ddhsml), P<double>(ctx->ddivv),
-        P<double>(ctx->drot), counter);
+      SPH_LAUNCH(k_density, tgw, nbk * nsub, st, t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur,
+                 nsub, cur, hcur, b, P<double>(ctx->drho), P<double>(ctx->dnumngb),
+                 P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), counter);
       k_dens_finalize<<<cdiv(ncur, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
         ncur, nsub, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
         P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
@@ -755,7 +833,7 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
-  k_density<<<nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
+  k_density<8><<<nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
                               P<double>(ctx->drho), P<double>(ctx->dnumngb),
                               P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot),
                               counter);
@@ -956,21 +1034,24 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
     }
 }
 
-// hydro_evaluate (hydra.c:822-1995, mode 0) for a bucket of 64 curve-consecutive targets, same
-// structure as k_density: scalar node records, candidate records (gp + gq, 128 B) staged through
-// LDS 64 at a time, exact per-lane acceptance r2 < h_i^2 || r2 < h_j^2.  Node pruning uses
-// max(hmax_node, h_i) like ngb_treefind_pairs (ngb.c:136).  Outputs: [5][nt] planes.
+// hydro_evaluate (hydra.c:822-1995, mode 0) for a bucket of TG curve-consecutive targets x 64/TG
+// candidate slots, same structure as k_density: scalar node records, candidate records (gp + gq,
+// 128 B) staged through LDS 64 at a time, exact per-lane acceptance r2 < h_i^2 || r2 < h_j^2.  Node
+// pruning uses max(hmax_node, h_i) like ngb_treefind_pairs (ngb.c:136).  Outputs: [5][nt] planes.
+template <int TG>
 __global__ void __launch_bounds__(64)
 k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp,
         const double *__restrict__ gq, int nt, int nsub, const int *__restrict__ tgt, BoxK b, HydK K,
         double *__restrict__ part, unsigned long long *__restrict__ counter)
 {
+  constexpr int CS = 64 / TG;
   __shared__ double4 sh[SPH_STAGE][4];
   const int lane = threadIdx.x;
+  const int tl = lane & (TG - 1), cs = lane / TG;
   const int bucket = blockIdx.x / nsub;
   const int sub = blockIdx.x - bucket * nsub;
   int batch = 0;
-  const int ti = bucket * 64 + lane;
+  const int ti = bucket * TG + tl;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
   HydTgt T = {0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 0};
@@ -1010,7 +1091,7 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
       if(pidx >= 0)
         {
           if((batch++ % nsub) == sub)
-            d_hydro_pair(gp + (size_t) 8 * pidx, gq + (size_t) 8 * pidx, valid, T, K, b, A);
+            d_hydro_pair(gp + (size_t) 8 * pidx, gq + (size_t) 8 * pidx, valid && cs == 0, T, K, b, A);
           e = e + 1;
         }
       else
@@ -1024,36 +1105,36 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
               if(pcount <= SPH_LEAF)
                 {
                   for(int r0 = 0; r0 < pcount; r0 += SPH_STAGE)
-                  if((batch++ % nsub) == sub)
-                    {
-                  const bool staged = r0 + lane < pcount;
-                  __syncthreads();
-                  double4 c0 = make_double4(0, 0, 0, 0), c1 = make_double4(0, 0, 0, 0);
-                  if(staged)
-                    {
-                      const double4 *s0 =
-                        reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + r0 + lane));
-                      const double4 *s1 =
-                        reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + r0 + lane));
-                      c0 = s0[0];
-                      c1 = s0[1];
-                      sh[lane][0] = c0;
-                      sh[lane][1] = c1;
-                      sh[lane][2] = s1[0];
-                      sh[lane][3] = s1[1];
-                    }
-                  // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
-                  unsigned long long live =
-                    d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c1.w, b);
-                  __syncthreads();
-                  while(live)
-                    {
-                      const int j = __builtin_ctzll(live);
-                      live &= live - 1;
-                      d_hydro_pair(reinterpret_cast<const double *>(&sh[j][0]),
-                                   reinterpret_cast<const double *>(&sh[j][2]), valid, T, K, b, A);
-                    }
-                    }
+                    if((batch++ % nsub) == sub)
+                      {
+                        const bool staged = r0 + lane < pcount;
+                        __syncthreads();
+                        double4 c0 = make_double4(0, 0, 0, 0), c1 = make_double4(0, 0, 0, 0);
+                        if(staged)
+                          {
+                            const double4 *s0 =
+                              reinterpret_cast<const double4 *>(gp + (size_t) 8 * (pstart + r0 + lane));
+                            const double4 *s1 =
+                              reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + r0 + lane));
+                            c0 = s0[0];
+                            c1 = s0[1];
+                            sh[lane][0] = c0;
+                            sh[lane][1] = c1;
+                            sh[lane][2] = s1[0];
+                            sh[lane][3] = s1[1];
+                          }
+                        // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
+                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c1.w, b);
+                        __syncthreads();
+                        while(live)
+                          {
+                            const int j = d_next_candidates<CS>(live, cs);
+                            const int jj = j < 0 ? 0 : j;
+                            d_hydro_pair(reinterpret_cast<const double *>(&sh[jj][0]),
+                                         reinterpret_cast<const double *>(&sh[jj][2]), valid && j >= 0, T,
+                                         K, b, A);
+                          }
+                      }
                   e = skip;
                 }
               else
@@ -1063,15 +1144,17 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
             e = skip;
         }
     }
-  if(valid)
+  const double ax = d_slot_sum<TG>(A.ax), ay = d_slot_sum<TG>(A.ay), az = d_slot_sum<TG>(A.az);
+  const double de = d_slot_sum<TG>(A.dtent), ms = d_slot_max<TG>(A.maxsig);
+  if(valid && cs == 0)
     {
       const size_t plane = (size_t) nsub * nt;
       const size_t o = (size_t) sub * nt + ti;
-      part[o] = A.ax;
-      part[plane + o] = A.ay;
-      part[2 * plane + o] = A.az;
-      part[3 * plane + o] = A.dtent;
-      part[4 * plane + o] = A.maxsig;
+      part[o] = ax;
+      part[plane + o] = ay;
+      part[2 * plane + o] = az;
+      part[3 * plane + o] = de;
+      part[4 * plane + o] = ms;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.np);
   if(lane == 0 && tot)
@@ -1139,13 +1222,14 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   if(ctx->grav_pending && !getenv("GHIP_HYDRO_EARLY"))
     HIPCHK(hipStreamWaitEvent(st, ctx->evx[3], 0));
   HIPCHK(hipEventRecord(ctx->ev[10], st));
-  const int nbk = (nt + 63) / 64;
+  const int tgw = ghip_sph_tg();
+  const int nbk = (nt + tgw - 1) / tgw;
   int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
   nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
   GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
-  k_hydro<<<nbk * nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp),
-                                     P<double>(ctx->gq), nt, nsub, P<int>(ctx->tg_gas) + lo, b, K,
-                                     P<double>(ctx->hpart), counter);
+  SPH_LAUNCH(k_hydro, tgw, nbk * nsub, st, t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp),
+             P<double>(ctx->gq), nt, nsub, P<int>(ctx->tg_gas) + lo, b, K, P<double>(ctx->hpart),
+             counter);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[11], st));
   k_hydro_combine<<<cdiv(nt, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
