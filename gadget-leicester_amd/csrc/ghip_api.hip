@@ -213,7 +213,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
                   &ctx->dleft,  &ctx->dright, &ctx->drho,    &ctx->dnumngb, &ctx->ddhsml,
                   &ctx->ddivv,  &ctx->drot,   &ctx->dflags,  &ctx->dtgt_a,  &ctx->dtgt_b,
                   &ctx->act_host_idx, &ctx->tg_grav, &ctx->tg_gas, &ctx->tax, &ctx->tay,
-                  &ctx->taz,    &ctx->tcost,  &ctx->ewtab,   &ctx->srtab,   &ctx->cubtmp,
+                  &ctx->taz,    &ctx->tcost,  &ctx->ewtab,   &ctx->ewbrick, &ctx->srtab,   &ctx->cubtmp,
                   &ctx->counters, &ctx->dhcur, &ctx->hpart, &ctx->plan_nsub, &ctx->plan_woff,
                   &ctx->plan_wave, &ctx->plan_steps[0][0], &ctx->plan_steps[0][1],
                   &ctx->plan_steps[1][0], &ctx->plan_steps[1][1], &ctx->plan_steps[2][0],

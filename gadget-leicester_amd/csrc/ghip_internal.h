@@ -13,6 +13,19 @@
 
 #define GHIP_BITS 21       // BITS_PER_DIMENSION, allvars.h:58
 #define GHIP_EN 64         // EN, forcetree.c:51
+// A second copy of the Ewald table is brick-tiled: one 128-byte line holds the values of 2 (first
+// index) x 2 (second index) rows x 4 consecutive values of the last index, and consecutive bricks
+// along the last index OVERLAP by one value (3 cells per brick), so that the pair (k, k+1) of a cell
+// never straddles two lines.  Value (i, j, v) sits in brick (i>>1, j>>1, v/3) at
+// ((i&1)*2 + (j&1))*4 + v%3 -- and, for v%3 == 0 and v > 0, also in slot 3 of brick v/3 - 1.
+#define GHIP_EW_NB ((GHIP_EN >> 1) + 1)   // bricks along the first and the second index (values 0..EN)
+#define GHIP_EW_NKB (GHIP_EN / 3 + 1)     // bricks along the last index: 3 cells each
+#define GHIP_EW_DOUBLES (GHIP_EW_NB * GHIP_EW_NB * GHIP_EW_NKB * 16)
+static inline __host__ __device__ unsigned int ghip_ew_offset(int i, int j, int kb, int t)
+{
+  return (unsigned int) ((((i >> 1) * GHIP_EW_NB + (j >> 1)) * GHIP_EW_NKB + kb) * 16 +
+                         ((i & 1) * 2 + (j & 1)) * 4 + t);
+}
 #define GHIP_NTAB 1000     // NTAB, forcetree.c:28
 #define GHIP_WAVE 64
 #define GHIP_BLOCK 256
@@ -241,6 +254,7 @@ struct ghip_ctx
 
   // ewald
   DevBuf ewtab;   // double[(EN+1)^3]: fcorrx scaled by 1/Box^2 (y, z by symmetry)
+  DevBuf ewbrick; // the same values brick-tiled (GHIP_EW_DOUBLES), for the Ewald walk outside a pair
   double ew_box = 0;
   DevBuf srtab;   // float[NTAB]
   bool srtab_ready = false;

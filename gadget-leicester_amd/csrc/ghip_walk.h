@@ -177,7 +177,9 @@ __device__ __forceinline__ double d_grav_fac(double mass, double r2, double h, d
           0.066666666667 / (u * u * u));
 }
 
-// trilinear Ewald look-up, forcetree.c:3097-3170.  tab: double4 (fx,fy,fz,0) per grid point.
+// trilinear Ewald look-up, forcetree.c:3097-3170, from the one-component table: plain rows of EN+1
+// values, or (BRICK) the brick-tiled copy.
+template <bool BRICK>
 __device__ __forceinline__ void d_ewald_interp(const double *__restrict__ tab, double fac_intp,
                                                double dx, double dy, double dz, double &fx,
                                                double &fy, double &fz)
@@ -222,15 +224,46 @@ __device__ __forceinline__ void d_ewald_interp(const double *__restrict__ tab, d
   // fy(x,y,z) = fx(y,x,z) and fz(x,y,z) = fx(z,y,x), so tab holds fx only (2.2 MB instead of
   // 6.6 MB: it stays in the 4 MB L2 of an XCD).  Two neighbouring entries along the last index
   // come with one 16-byte load.  Weights: f1..f8 = W[a][b][c] for the corner (i+a, j+b, k+c).
-  const double *bx = tab + ((size_t) i * E1 + j) * E1 + k;
-  const double *by = tab + ((size_t) j * E1 + i) * E1 + k;
-  const double *bz = tab + ((size_t) k * E1 + j) * E1 + i;
-  const EwPair x00 = d_ldpair(bx), x01 = d_ldpair(bx + E1), x10 = d_ldpair(bx + E1 * E1),
-               x11 = d_ldpair(bx + E1 * E1 + E1);
-  const EwPair y00 = d_ldpair(by), y01 = d_ldpair(by + E1), y10 = d_ldpair(by + E1 * E1),
-               y11 = d_ldpair(by + E1 * E1 + E1);
-  const EwPair z00 = d_ldpair(bz), z01 = d_ldpair(bz + E1), z10 = d_ldpair(bz + E1 * E1),
-               z11 = d_ldpair(bz + E1 * E1 + E1);
+  EwPair x00, x01, x10, x11, y00, y01, y10, y11, z00, z01, z10, z11;
+  if(!BRICK)
+    {
+      const double *bx = tab + ((size_t) i * E1 + j) * E1 + k;
+      const double *by = tab + ((size_t) j * E1 + i) * E1 + k;
+      const double *bz = tab + ((size_t) k * E1 + j) * E1 + i;
+      x00 = d_ldpair(bx), x01 = d_ldpair(bx + E1), x10 = d_ldpair(bx + E1 * E1),
+      x11 = d_ldpair(bx + E1 * E1 + E1);
+      y00 = d_ldpair(by), y01 = d_ldpair(by + E1), y10 = d_ldpair(by + E1 * E1),
+      y11 = d_ldpair(by + E1 * E1 + E1);
+      z00 = d_ldpair(bz), z01 = d_ldpair(bz + E1), z10 = d_ldpair(bz + E1 * E1),
+      z11 = d_ldpair(bz + E1 * E1 + E1);
+    }
+  else
+    {
+      // brick-tiled (ghip_internal.h): 2 x 2 rows x 3 cells of the last index per 128-byte line, so
+      // the 64 lanes of a wavefront -- whose cells differ by a few units in every index -- fall into
+      // fewer lines than with rows of 65 values.  Byte offset of a value: A(first index) +
+      // B(second index) + C(last index).
+      const unsigned int SA = GHIP_EW_NB * GHIP_EW_NKB * 128, SB = GHIP_EW_NKB * 128;
+      const unsigned int ai = (i >> 1) * SA + (i & 1) * 64, ai1 = ((i + 1) >> 1) * SA + ((i + 1) & 1) * 64;
+      const unsigned int aj = (j >> 1) * SA + (j & 1) * 64, aj1 = ((j + 1) >> 1) * SA + ((j + 1) & 1) * 64;
+      const unsigned int ak = (k >> 1) * SA + (k & 1) * 64, ak1 = ((k + 1) >> 1) * SA + ((k + 1) & 1) * 64;
+      const unsigned int bi = (i >> 1) * SB + (i & 1) * 32, bi1 = ((i + 1) >> 1) * SB + ((i + 1) & 1) * 32;
+      const unsigned int bj = (j >> 1) * SB + (j & 1) * 32, bj1 = ((j + 1) >> 1) * SB + ((j + 1) & 1) * 32;
+      // last index: brick v/3, slot v%3  ->  (v/3)*16 + v - 3*(v/3) = (v/3)*13 + v   (v < 128)
+      const unsigned int ck = ((((unsigned int) k * 43u) >> 7) * 13u + (unsigned int) k) * 8u;
+      const unsigned int ci = ((((unsigned int) i * 43u) >> 7) * 13u + (unsigned int) i) * 8u;
+      const char *tb = reinterpret_cast<const char *>(tab);
+#define EW_LD(off) d_ldpair(reinterpret_cast<const double *>(tb + (off)))
+      // x: T[i+a][j+b][k..k+1];  y: T[j+b][i+a][k..k+1] (y<first index offset><second index offset>);
+      // z: T[k+c][j+b][i..i+1]
+      x00 = EW_LD(ai + bj + ck), x01 = EW_LD(ai + bj1 + ck), x10 = EW_LD(ai1 + bj + ck),
+      x11 = EW_LD(ai1 + bj1 + ck);
+      y00 = EW_LD(aj + bi + ck), y01 = EW_LD(aj + bi1 + ck), y10 = EW_LD(aj1 + bi + ck),
+      y11 = EW_LD(aj1 + bi1 + ck);
+      z00 = EW_LD(ak + bj + ci), z01 = EW_LD(ak + bj1 + ci), z10 = EW_LD(ak1 + bj + ci),
+      z11 = EW_LD(ak1 + bj1 + ci);
+#undef EW_LD
+    }
   // fx: rows (a,b), pair over c
   fx = sx * (x00.lo * f1 + x00.hi * f2 + x01.lo * f3 + x01.hi * f4 + x10.lo * f5 + x10.hi * f6 +
              x11.lo * f7 + x11.hi * f8);
@@ -434,7 +467,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
       if(MODE == GHIP_WALK_EWALD)
         {
           double fx, fy, fz;
-          d_ewald_interp(ewtab, p.fac_intp, dx, dy, dz, fx, fy, fz);
+          d_ewald_interp<UNEQUAL>(ewtab, p.fac_intp, dx, dy, dz, fx, fy, fz);   // (UNEQUAL: brick table)
           W.acc_x += mass * fx;
           W.acc_y += mass * fy;
           W.acc_z += mass * fz;
