@@ -378,7 +378,18 @@ def main():
             out["dropin_ms_per_step"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pr.ti_current = tl.ti
-        out["cpu_baseline"] = cpu_baseline(pr, fp, B, args)
+
+        def device_eval():
+            # one more force evaluation of the state the run reached, nothing advanced
+            dp = pr.g_dens()
+            dp.Ti_Current, dp.Timebase_interval = tl.ti, tl.tb
+            fp.tree_build(*tree_args)
+            fp.gravity(gp_rel, B.WALK_NEWTON_EWALD)
+            fp.density(dp)
+            fp.update_hmax()
+            fp.hydro(hp)
+
+        out["cpu_baseline"] = cpu_baseline(pr, fp, B, args, device_eval)
 
     if rank == 0:
         sys.stdout.flush()
@@ -538,10 +549,12 @@ def pm_timing(pr, fp, pmgrid=128, reps=5):
             "algorithmic_bytes": nbytes}
 
 
-def cpu_baseline(pr, fp, B, args):
+def cpu_baseline(pr, fp, B, args, device_eval=None):
     """The CPU restatement of the force path (oracle/, kind "port"), timed on the host cores of
     this box on the FULL workload in the state the device run left it: same positions, smoothing
-    lengths and OldAcc, so both sides do the same work (same interaction sets)."""
+    lengths and OldAcc, so both sides do the same work (same interaction sets).  With device_eval the
+    device evaluates the same state once more and BASELINE's accuracy metric (max |da| / |a| over all
+    particles) is reported next to the timing."""
     from oracle import oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
@@ -560,6 +573,12 @@ def cpu_baseline(pr, fp, B, args):
     timebin = fp.get_field(B.F_TIMEBIN)
     tibeg = fp.get_field(B.F_TI_BEGSTEP)
     tab = np.ascontiguousarray(fp.ewald_table())      # identical to the oracle's to 1e-12
+    dev = None
+    if device_eval is not None:
+        device_eval()
+        dev = {"acc": fp.get_field(B.F_GRAVACCEL), "cost": fp.get_field(B.F_GRAVCOST),
+               "density": fp.get_field(B.F_DENSITY), "hsml": fp.get_field(B.F_HSML)[:ng],
+               "hydro": fp.get_field(B.F_HYDROACCEL), "dtentropy": fp.get_field(B.F_DTENTROPY)}
     tg = np.arange(n, dtype=np.int32)
     act = np.arange(ng, dtype=np.int32)
     t0 = time.perf_counter()
@@ -568,10 +587,28 @@ def cpu_baseline(pr, fp, B, args):
     T.gravity_ewald_add(pr.o_grav(0.0), tab, tg, oldacc, acc, cost)
     od = T.density(pr.o_dens(), act, velpred, entropy, dtentropy, timebin, tibeg, hs)
     T.update_hmax(act, od["hsml"], od["divvel"])
-    T.hydro(pr.o_hydro(), act, velpred, od["hsml"], od["density"], od["pressure"],
-            od["dhsmlfac"], od["divvel"], od["curlvel"], timebin)
+    oh = T.hydro(pr.o_hydro(), act, velpred, od["hsml"], od["density"], od["pressure"],
+                 od["dhsmlfac"], od["divvel"], od["curlvel"], timebin)
     dt = time.perf_counter() - t0
+    accuracy = None
+    if dev is not None:
+        def vrel(a, b):
+            return float((np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)).max())
+        tot_d, tot_o = pr.G * dev["acc"], pr.G * acc
+        tot_d[:ng] += dev["hydro"]
+        tot_o[:ng] += oh["hydroaccel"][:ng]
+        accuracy = {
+            "max_rel_dacc_gravity": vrel(dev["acc"], acc),
+            "max_rel_dacc_total": vrel(tot_d, tot_o),
+            "max_rel_density": float(np.abs(dev["density"] / od["density"][:ng] - 1).max()),
+            "max_rel_hsml": float(np.abs(dev["hsml"] / od["hsml"][:ng] - 1).max()),
+            "max_dtentropy_over_max": float(np.abs(dev["dtentropy"] - oh["dtentropy"][:ng]).max() /
+                                            np.abs(oh["dtentropy"][:ng]).max()),
+            "interaction_counts_equal": bool(np.array_equal(dev["cost"], cost)),
+            "target": "max |da|/|a| < 1e-5 (BASELINE north star); all %d particles, device vs the "
+                      "CPU port on the same state" % n}
     return {"value": n / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "accuracy_vs_cpu": accuracy,
             "sample": "one full force step (tree build + Newtonian + Ewald walks + density + hydro) "
                       "of the same %d-particle workload in the state the device run reached, "
                       "%.2f s wall on %d OpenMP threads" % (n, dt, threads),
