@@ -509,9 +509,13 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   if(lds_n < 0)
     lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 8192;
   // (only when the launch is large enough to fill the chip by itself: a small share of a
-  // multi-GPU run leaves room anyway -- measured break-even at about a quarter of c2's buckets)
+  // multi-GPU run leaves room anyway -- measured on c2's shards: 2048 buckets (4 shards) 4.0 -> 3.7 ms
+  // with the cap, 1024 buckets (8 shards) 2.38 -> 2.45 ms)
+  static int cap_min = -1;
+  if(cap_min < 0)
+    cap_min = getenv("GHIP_PAIR_CAP_MIN") ? atoi(getenv("GHIP_PAIR_CAP_MIN")) : 1536;
   const size_t dyn_lds =
-    (MODE == GHIP_WALK_NEWTON && stream != ctx->stream && nbuckets >= 3072) ? (size_t) lds_n : 0;
+    (MODE == GHIP_WALK_NEWTON && stream != ctx->stream && nbuckets >= cap_min) ? (size_t) lds_n : 0;
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
@@ -525,7 +529,7 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   static int brick_env = -2;
   if(brick_env == -2)
     brick_env = getenv("GHIP_EW_BRICK") ? atoi(getenv("GHIP_EW_BRICK")) : -1;
-  const bool in_full_pair = stream != ctx->stream && nbuckets >= 3072;
+  const bool in_full_pair = stream != ctx->stream && nbuckets >= cap_min;
   const bool brick = brick_env >= 0 ? brick_env != 0 : !in_full_pair;
   const bool uneq = (MODE == GHIP_WALK_EWALD) ? brick : (bool) k.unequal;
   if(k.periodic && uneq)

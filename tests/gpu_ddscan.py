@@ -72,6 +72,10 @@ def main():
             print("   %-26s max %.3f  mean %.3f" % (nm, max(r), float(np.mean(r))))
         print("   imported tree elements %s, ghosts %s" % ([i["let_imported"] for i in info],
                                                           [i["ghosts_imported"] for i in info]))
+        st = S.each(lambda fp: fp.stats())
+        print("   walk kernels per shard (ms): newton %s  ewald %s; tree %s" % (
+            ["%.2f" % s_["ms_grav"] for s_ in st], ["%.2f" % s_["ms_ewald"] for s_ in st],
+            ["%.2f" % s_["ms_tree"] for s_ in st]))
         if base is None:
             base = tot
         print("   speed-up over P=%d: %.2f" % (Ps[0], base / tot), flush=True)
