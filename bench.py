@@ -374,6 +374,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_dropin:
         try:
             out["dropin_ms_per_step"] = dropin_timing(pr)
+            out["dropin_ms_per_step"]["with_overlap_sph"] = dropin_timing(pr, overlap_sph=1)
         except Exception as e:
             out["dropin_ms_per_step"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -470,7 +471,7 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
     return r
 
 
-def dropin_timing(pr_bench, reps=3):
+def dropin_timing(pr_bench, reps=3, overlap_sph=0):
     """The PCIe-inclusive drop-in path accel.c would see: gravity_tree(), density(),
     force_update_hmax(), hydro_force() of libgadget_force.so on AoS P[]/SphP[] records, each with its
     H2D / D2H of the record blocks (SURVEY 8d's metric "including host<->device packing").  Never part
@@ -479,9 +480,10 @@ def dropin_timing(pr_bench, reps=3):
     from test_gpu_parity import _host_problem
     H = importlib.import_module("gadget-leicester_amd.hostapi")
     pr = Problem(ng=round((pr_bench.n // 2) ** (1 / 3)), gas=True, periodic=1)
-    host, P, S = _host_problem(pr, H, 1)
+    host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap_sph)
     L = host.L
     L.gravity_tree()                             # Barnes-Hut pass for OldAcc
+    L.gadget_force_flush()
     best = None
     for _ in range(reps):
         host.All.ErrTolTheta = 0
@@ -497,8 +499,12 @@ def dropin_timing(pr_bench, reps=3):
     return {"total": sum(best), "gravity_tree": best[0], "density": best[1],
             "force_update_hmax": best[2], "hydro_force": best[3], "ok": ok,
             "particle_steps_per_s": pr.n / (1e-3 * sum(best)),
+            "overlap_sph": overlap_sph,
             "note": "host calls the four drivers one after the other on 112-B / 184-B records; "
-                    "each uploads / downloads the record blocks over PCIe"}
+                    "each uploads / downloads the record blocks over PCIe"
+                    + ("; gadget_force_config.overlap_sph: the gravity walks stay in flight underneath "
+                       "density / hydro_force and their results arrive with hydro_force()"
+                       if overlap_sph else "")}
 
 
 def kick_roofline(pr, fp, B, reps=5):

@@ -200,6 +200,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(!ctx)
     return;
   (void) hipSetDevice(ctx->device);
+
   if(ctx->stream)
     (void) hipStreamSynchronize(ctx->stream);
   if(ctx->stream2)
@@ -477,7 +478,7 @@ __global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, in
   do                                                                                          \
     {                                                                                         \
       if((off) >= 0 && (cnt) > 0)                                                             \
-        k_pack_f64<<<cdiv((long long) (cnt), 256), 256, 0, st>>>(                             \
+        k_pack_f64<<<cdiv((long long) (cnt), ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(           \
           (size_t) (cnt), (char *) (img), (stride), (off), (ncomp), P<double>(ctx->f[fld]));  \
     }                                                                                         \
   while(0)
@@ -553,7 +554,8 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
 extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
                                  int want_gravity, int want_density, int want_hydro)
 {
-  if(ctx)
+  // the SPH results do not depend on a gravity pair still in flight underneath them
+  if(ctx && want_gravity)
     GHIP_JOIN(ctx);
   if(!ctx || !lay)
     return GHIP_EINVAL;
@@ -675,6 +677,10 @@ extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const g
 // ---------------------------------------------------------------------------------------------
 extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
 {
+  // "everybody" while everybody already is: nothing changes, and a gravity pair in flight (whose
+  // target lists this call would otherwise rebuild) need not be waited for
+  if(ctx && !idx && ctx->nactive < 0 && (nactive == 0 || nactive == ctx->n))
+    return GHIP_OK;
   if(ctx)
     GHIP_JOIN(ctx);
   if(!ctx || nactive < 0)

@@ -52,6 +52,8 @@ static void (*EndrunHandler)(int) = NULL;
 static int DeviceFresh = 0;      /* device copy of P/SphP matches the host arrays */
 static int TreeOnDevice = 0;
 static int Phase = 0;            /* 1 after gravity_tree(), 2 after density(): accel.c:61-106 order */
+static int GravPending = 0;      /* overlap_sph: walks in flight, post-pass + download still to do */
+static int GravPendingActive = 0;
 static int *ActiveBuf = NULL;
 static int ActiveCap = 0;
 static int NgblistCap = 0;
@@ -147,6 +149,8 @@ void gadget_force_finalize(void)
   NgblistCap = 0;
   DeviceFresh = 0;
   TreeOnDevice = 0;
+  Phase = 0;
+  GravPending = 0;
   /* the host's arrays are the host's: forget them, a later init must set them again */
   Nodes_base = Nodes = NULL;
   Extnodes_base = Extnodes = NULL;
@@ -584,12 +588,57 @@ static int ensure_tree(void)
   return 0;
 }
 
+/* the tail of gravity_tree(): post-pass on the device, results into P[] (download != 0: by a
+ * download of their own; 0: the caller downloads them together with its own results) */
+static int gravity_complete(int download)
+{
+  GravPending = 0;
+  /* gravtree.c:362-403: the comoving term of non-periodic builds without a PM mesh, then
+   * OldAcc = |GravAccel (+ GravPM / G)|, then the multiplication by G */
+  double comoving_fac = 0;
+  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn)
+    comoving_fac = 0.5 * All.Hubble * All.Hubble * All.Omega0 / All.G;
+  if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
+    return -1;
+  if(All.TypeOfOpeningCriterion == 1)
+    {
+      All.ErrTolTheta = 0; /* gravtree.c:396-397 */
+      all_push();
+    }
+  /* gravtree.c:470-483: vacuum energy in physical coordinates */
+  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn == 0)
+    if(chk(ghip_gravity_vacuum_energy(Ctx, All.OmegaLambda * All.Hubble * All.Hubble),
+           "ghip_gravity_vacuum_energy"))
+      return -1;
+  if(download)
+    {
+      ghip_layout lay;
+      gadget_force_layout(&lay);
+      if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))
+        return -1;
+    }
+  All.TotNumOfForces += GravPendingActive;
+  all_push();
+  return 0;
+}
+
+void gadget_force_flush(void)
+{
+  if(GravPending && Ctx)
+    {
+      all_pull();
+      gravity_complete(1);
+    }
+}
+
 /* gravtree.c:27-828 */
 void gravity_tree(void)
 {
   if(need_ctx("gravity_tree"))
     return;
   double t0 = wallclock();
+  if(GravPending && gravity_complete(1))   /* accel.c:63-64: the second pass of step 0 needs OldAcc */
+    return;
   /* gravtree.c:55-56 */
   if(All.ComovingIntegrationOn)
     set_softenings();
@@ -614,29 +663,19 @@ void gravity_tree(void)
     walk = GHIP_WALK_NEWTON_EWALD; /* both passes in one call: the two walks share the device */
   if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
     return;
-  /* gravtree.c:362-403: the comoving term of non-periodic builds without a PM mesh, then
-   * OldAcc = |GravAccel (+ GravPM / G)|, then the multiplication by G */
-  double comoving_fac = 0;
-  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn)
-    comoving_fac = 0.5 * All.Hubble * All.Hubble * All.Omega0 / All.G;
-  if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
-    return;
-  if(All.TypeOfOpeningCriterion == 1)
+  GravPendingActive = nact;
+  /* overlap_sph: with gas to work on and everybody active (no list changes until hydro_force), the
+   * walks stay in flight and the SPH phases run underneath them; the post-pass and the download
+   * follow in hydro_force() / gadget_force_flush() */
+  if(Cfg.overlap_sph && walk == GHIP_WALK_NEWTON_EWALD && N_gas > 0 && nact == NumPart)
     {
-      All.ErrTolTheta = 0; /* gravtree.c:396-397 */
-      all_push();
-    }
-  /* gravtree.c:470-483: vacuum energy in physical coordinates */
-  if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn == 0)
-    if(chk(ghip_gravity_vacuum_energy(Ctx, All.OmegaLambda * All.Hubble * All.Hubble),
-           "ghip_gravity_vacuum_energy"))
+      GravPending = 1;
+      Phase = 1;
+      CPU_Step_Treewalk += wallclock() - t0;
       return;
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))
+    }
+  if(gravity_complete(1))
     return;
-  All.TotNumOfForces += nact;
-  all_push();
   Phase = 1;
   CPU_Step_Treewalk += wallclock() - t0;
 }
@@ -677,6 +716,12 @@ static int refuse_non_gas_density_targets(const char *who)
   return 0;
 }
 
+/* every gas particle is an active target: "everybody" selects the same gas targets as the list */
+static int gravity_was_full_and_gas_is(int nact_gas)
+{
+  return N_gas > 0 && nact_gas == N_gas;
+}
+
 /* density.c:89-704 */
 void density(void)
 {
@@ -694,8 +739,14 @@ void density(void)
   int nact = collect_active(1);
   if(nact < 0)
     return;
-  /* an empty list must not mean "all": give the device a real (possibly empty) list */
-  if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
+  /* an empty list must not mean "all": give the device a real (possibly empty) list.  Everybody
+   * active stays "everybody" (no list: a gravity pair in flight is not disturbed). */
+  if(gravity_was_full_and_gas_is(nact))
+    {
+      if(chk(ghip_set_active(Ctx, NULL, 0), "ghip_set_active"))
+        return;
+    }
+  else if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
     return;
   ghip_dens_params d;
   fill_dens_params(&d);
@@ -737,15 +788,25 @@ void hydro_force(void)
   int nact = collect_active(1);
   if(nact < 0)
     return;
-  if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
+  if(gravity_was_full_and_gas_is(nact))
+    {
+      if(chk(ghip_set_active(Ctx, NULL, 0), "ghip_set_active"))
+        return;
+    }
+  else if(chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active"))
     return;
   ghip_hydro_params h;
   fill_hydro_params(&h, 0);
   if(chk(ghip_hydro(Ctx, &h), "ghip_hydro"))
     return;
+  /* overlap_sph: the gravity walks have been running underneath; their post-pass now, and one
+   * download for both */
+  const int with_gravity = GravPending;
+  if(with_gravity && gravity_complete(0))
+    return;
   ghip_layout lay;
   gadget_force_layout(&lay);
-  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 0, 0, 1), "ghip_download_aos"))
+  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, with_gravity, 0, 1), "ghip_download_aos"))
     return;
   Phase = 0;
   CPU_Step_Hydro += wallclock() - t0;
@@ -853,6 +914,7 @@ void advance_and_find_timesteps(void)
 {
   if(need_ctx("advance_and_find_timesteps"))
     return;
+  gadget_force_flush();   /* (overlap_sph without a hydro_force() call: the kick needs G * GravAccel) */
   if(All.TypeOfTimestepCriterion != 0)
     {
       endrun(888); /* timestep.c:726 */

@@ -64,7 +64,8 @@ class AllStruct(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("periodic", C.c_int), ("pmgrid", C.c_int), ("unequal_softenings", C.c_int),
-                ("device", C.c_int), ("black_holes", C.c_int), ("dust", C.c_int)]
+                ("device", C.c_int), ("black_holes", C.c_int), ("dust", C.c_int),
+                ("overlap_sph", C.c_int)]
 
 
 ENDRUN_CB = C.CFUNCTYPE(None, C.c_int)
@@ -150,12 +151,13 @@ class Host:
     """Owns the numpy arrays standing in for the reference's P[], SphP[], NextActiveParticle[]
     and points the library's globals at them."""
 
-    def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0, black_holes=0, dust=0):
+    def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0, black_holes=0, dust=0,
+                 overlap_sph=0):
         self.L = lib()
         self.endrun_codes = []
         self._cb = ENDRUN_CB(lambda code: self.endrun_codes.append(code))
         self.L.gadget_force_set_endrun(self._cb)
-        cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust)
+        cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust, overlap_sph)
         rc = self.L.gadget_force_init(C.byref(cfg))
         if rc != 0:
             raise RuntimeError("gadget_force_init failed (%d): %s" %

@@ -244,6 +244,13 @@ struct gadget_force_config
   int black_holes;         /* -DBLACK_HOLES (without NO_BH_ACCRETION): Type 5 is a density target
                               (density.c:1035-1041) */
   int dust;                /* -DDUST: Type 2 is a density target (density.c:1043-1046) */
+  int overlap_sph;         /* 1: on a step with gas, gravity_tree() returns with its walks still in
+                              flight and density() / force_update_hmax() / hydro_force() run underneath
+                              them on the device; the gravity results (GravAccel, OldAcc, GravCost)
+                              reach P[] when hydro_force() returns -- or gadget_force_flush().  Valid
+                              for accel.c's sequence (accel.c:61-106: nothing reads P[].g.GravAccel
+                              between the four calls); 0 (default): every driver returns with its own
+                              results in P[] / SphP[] */
 };
 
 /* ---- globals with the reference's names (allvars.c) ---- */
@@ -293,6 +300,8 @@ void gadget_force_set_kick_tables(const double *gravkick, const double *hydrokic
                                   double logTimeBegin, double logTimeMax);
 /* tell the glue that the host changed P/SphP outside the four drivers */
 void gadget_force_mark_dirty(void);
+/* overlap_sph: complete a gravity_tree() whose results are still on the device (no-op otherwise) */
+void gadget_force_flush(void);
 
 /* ---- the reference's call surface ---- */
 void endrun(int ierr);
