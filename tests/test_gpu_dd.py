@@ -447,9 +447,10 @@ def test_sharded_sph_variants(variant):
         S.close()
 
 
-def test_bench_two_ranks_share_one_gpu_through_the_host_transport():
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_ranks_share_one_gpu_through_the_host_transport(nranks):
     """The multi-process form of the domain-decomposed path, as the driver launches it
-    (torch.distributed.run, one rank per process): two ranks on this box's one GPU, which RCCL refuses
+    (torch.distributed.run, one rank per process): several ranks on this box's one GPU, which RCCL refuses
     (duplicate device), so every exchange is staged through the host and gloo
     (ghip_dd_exchange_host) -- the same state machine, migration included.  Checks the bench
     contract's JSON line and that no particle was lost."""
@@ -463,15 +464,15 @@ def test_bench_two_ranks_share_one_gpu_through_the_host_transport():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BENCH_TRANSPORT="host", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--ng", "24"]
+           "--gpus", str(nranks), "--steps", "3", "--warmup", "1", "--ng", "24"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+    assert out["n_gpus"] == nranks and out["steps"] == 3 and out["value"] > 0
     assert out["config"]["n_particles"] == 2 * 24 ** 3
     assert "domain decomposition" in out["config"]["parallelism"]
     x = out["exchange_per_step_rank0"]
