@@ -17,8 +17,8 @@ import sys
 KERNELS = {
     "k_grav_walk<NEWTON>": "void k_grav_walk<0, true",
     "k_grav_walk<EWALD>": "void k_grav_walk<2, true",
-    "k_density": "k_density(",
-    "k_hydro": "k_hydro(",
+    "k_density": ("k_density(", "void k_density<"),
+    "k_hydro": ("k_hydro(", "void k_hydro<"),
 }
 
 
@@ -33,7 +33,7 @@ def main():
         acc = {}
         for row in csv.DictReader(open(f)):
             for label, prefix in KERNELS.items():
-                if row["Kernel_Name"].startswith(prefix):
+                if row["Kernel_Name"].startswith(prefix):   # (str.startswith takes a tuple too)
                     key = (label, row["Counter_Name"])
                     seen[key] = seen.get(key, 0) + 1
                     if label.startswith("k_grav_walk") and seen[key] == 1:
