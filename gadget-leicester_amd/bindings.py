@@ -704,7 +704,7 @@ class ForcePath:
 
 # ---- multi-GPU module-level helpers ----
 DD_MIGRATE, DD_GRAVITY, DD_DENSITY, DD_HYDRO = 1, 2, 3, 4
-DD_SINK_DENSITY, DD_BH_EVALUATE, DD_BH_SWALLOW = 5, 6, 7
+DD_SINK_DENSITY, DD_BH_EVALUATE, DD_BH_SWALLOW, DD_PM = 5, 6, 7, 8
 
 
 class DdSinkArgs(C.Structure):

@@ -42,6 +42,8 @@ void ghip_dd_comm_release(ghip_ctx *ctx);
 // sink.hip
 int ghip_dd_sink_begin(ghip_ctx *ctx, int op);
 int ghip_dd_sink_step(ghip_ctx *ctx);
+int ghip_dd_pm_begin(ghip_ctx *ctx);   // ghip_pm.hip
+int ghip_dd_pm_step(ghip_ctx *ctx);
 extern "C" int ghip_dd_exchange(ghip_ctx *ctx);
 
 #define DD_OP_MIGRATE 1
@@ -1494,6 +1496,11 @@ extern "C" int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk
       D.sink = *reinterpret_cast<const ghip_dd_sink_args *>(params);
       GCHK(ghip_dd_sink_begin(ctx, op));
     }
+  else if(op == GHIP_DD_PM)
+    {
+      D.pm = *reinterpret_cast<const ghip_pm_params *>(params);
+      GCHK(ghip_dd_pm_begin(ctx));
+    }
   else if(op == DD_OP_MIGRATE)
     {
       static_assert(sizeof(MigRec) == MIG_SLOTS * 8, "MigRec layout");
@@ -1527,6 +1534,8 @@ extern "C" int ghip_dd_step(ghip_ctx *ctx)
   HIPCHK(hipSetDevice(ctx->device));
   if(D.op >= GHIP_DD_SINK_DENSITY && D.op <= GHIP_DD_BH_SWALLOW)
     return ghip_dd_sink_step(ctx);
+  if(D.op == GHIP_DD_PM)
+    return ghip_dd_pm_step(ctx);
   if(D.op == DD_OP_MIGRATE)
     return migrate_step(ctx);
   if(D.op == DD_OP_GRAVITY)
@@ -1592,7 +1601,7 @@ void ghip_dd_release(ghip_ctx *ctx)
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
                   &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,
                   &D.mig_send, &D.mig_recv, &D.mig_scan, &D.gas_src, &D.sk_send, &D.sk_all, &D.sk_part,
-                  &D.sk_parts, &D.sk_work};
+                  &D.sk_parts, &D.sk_work, &D.pm_all};
   for(DevBuf *b : bs)
     {
       if(b->p)

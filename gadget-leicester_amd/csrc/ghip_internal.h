@@ -167,7 +167,9 @@ struct DDState
   int sk_total = 0, sk_off = 0, sk_iter = 0, sk_ncur = 0;
   SinkIter sk_it;                 // h iteration state of ALL sinks (identical on all ranks)
   // traffic of the last operation (bytes this rank sent over links, excluding its own block)
-  long long bytes_sent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long bytes_sent[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ghip_pm_params pm;              // GHIP_DD_PM
+  DevBuf pm_all;                  // the density meshes of all shards
 };
 
 // the pending exchange of a state-machine step (ghip_dd.hip, ghip_sink.hip)

@@ -170,18 +170,17 @@ __global__ void k_pm_interpolate(int n, int N, double to_slab_fac, const double 
     gravpm[(size_t) dim * n + i] += acc[dim];
 }
 
-extern "C" int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p)
+static int pm_check(ghip_ctx *ctx, const ghip_pm_params *p)
 {
-  if(ctx)
-    GHIP_JOIN(ctx);
-  if(!ctx || !p)
-    return GHIP_EINVAL;
   const int N = p->pmgrid;
   if(N < 4 || N > 2048 || (N & 1) || !(p->BoxSize > 0) || !(p->Asmth > 0))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_pm_periodic: need an even PMGRID >= 4, BoxSize > 0, Asmth > 0");
-  const int n = ctx->n;
-  if(n == 0)
-    return GHIP_OK;
+  return GHIP_OK;
+}
+
+// plans and mesh buffers for PMGRID = N
+static int pm_prepare(ghip_ctx *ctx, int N)
+{
   hipStream_t st = ctx->stream;
   const size_t n3 = (size_t) N * N * N, nk = (size_t) N * N * (N / 2 + 1);
   if(ctx->pm_n != N)
@@ -204,29 +203,120 @@ extern "C" int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p)
   GCHK(ghip_ensure(ctx, ctx->pm_rho, n3 * sizeof(double)));
   GCHK(ghip_ensure(ctx, ctx->pm_k, nk * sizeof(double2)));
   GCHK(ghip_ensure(ctx, ctx->pm_force, 3 * n3 * sizeof(double)));
+  return GHIP_OK;
+}
+
+// mass of this context's particles onto the (zeroed) mesh; GRAVPM zeroed as long_range_force() does
+static int pm_deposit(ghip_ctx *ctx, const ghip_pm_params *p)
+{
+  hipStream_t st = ctx->stream;
+  const int N = p->pmgrid, n = ctx->n;
+  const size_t n3 = (size_t) N * N * N;
+  const double to_slab_fac = N / p->BoxSize;                   // pm_periodic.c:102
+  double *rho = P<double>(ctx->pm_rho);
+  HIPCHK(hipMemsetAsync(rho, 0, n3 * sizeof(double), st));
+  if(n > 0)
+    {
+      HIPCHK(hipMemsetAsync(ctx->f[GHIP_F_GRAVPM].p, 0, (size_t) n * 3 * sizeof(double), st));
+      k_pm_deposit<<<cdiv(n, 256), 256, 0, st>>>(n, N, to_slab_fac, P<double>(ctx->f[GHIP_F_POS]),
+                                                 P<double>(ctx->f[GHIP_F_MASS]), rho);
+      HIPCHK(hipGetLastError());
+    }
+  return GHIP_OK;
+}
+
+// mesh density -> potential -> force field -> GRAVPM of this context's particles
+static int pm_solve_and_interpolate(ghip_ctx *ctx, const ghip_pm_params *p)
+{
+  hipStream_t st = ctx->stream;
+  const int N = p->pmgrid, n = ctx->n;
+  const size_t n3 = (size_t) N * N * N, nk = (size_t) N * N * (N / 2 + 1);
   double *rho = P<double>(ctx->pm_rho), *force = P<double>(ctx->pm_force);
   double2 *fk = P<double2>(ctx->pm_k);
-  const double to_slab_fac = N / p->BoxSize;                   // pm_periodic.c:102
+  const double to_slab_fac = N / p->BoxSize;
   double asmth2 = (2 * M_PI) * p->Asmth / p->BoxSize;          // :221-222
   asmth2 *= asmth2;
   double fac = p->G / (M_PI * p->BoxSize);                     // :224-225
   fac *= 1 / (2 * p->BoxSize / N);
-  HIPCHK(hipEventRecord(ctx->ev[14], st));
-  HIPCHK(hipMemsetAsync(rho, 0, n3 * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(ctx->f[GHIP_F_GRAVPM].p, 0, (size_t) n * 3 * sizeof(double), st));   // long_range_force()
-  k_pm_deposit<<<cdiv(n, 256), 256, 0, st>>>(n, N, to_slab_fac, P<double>(ctx->f[GHIP_F_POS]),
-                                             P<double>(ctx->f[GHIP_F_MASS]), rho);
-  HIPCHK(hipGetLastError());
   FFTCHK(hipfftExecD2Z((hipfftHandle) ctx->pm_fwd, rho, reinterpret_cast<hipfftDoubleComplex *>(fk)));
   k_pm_green<<<cdiv((long long) nk, 256), 256, 0, st>>>(N, asmth2, fk);
   HIPCHK(hipGetLastError());
   FFTCHK(hipfftExecZ2D((hipfftHandle) ctx->pm_inv, reinterpret_cast<hipfftDoubleComplex *>(fk), rho));
   k_pm_gradient<<<cdiv((long long) n3, 256), 256, 0, st>>>(N, fac, rho, force);
-  k_pm_interpolate<<<cdiv(n, 256), 256, 0, st>>>(n, N, to_slab_fac, P<double>(ctx->f[GHIP_F_POS]),
-                                                 force, P<double>(ctx->f[GHIP_F_GRAVPM]));
+  if(n > 0)
+    k_pm_interpolate<<<cdiv(n, 256), 256, 0, st>>>(n, N, to_slab_fac, P<double>(ctx->f[GHIP_F_POS]),
+                                                   force, P<double>(ctx->f[GHIP_F_GRAVPM]));
   HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+extern "C" int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  if(!ctx || !p)
+    return GHIP_EINVAL;
+  GCHK(pm_check(ctx, p));
+  if(ctx->dd.on)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_pm_periodic: on a multi-GPU shard use GHIP_DD_PM");
+  if(ctx->n == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  GCHK(pm_prepare(ctx, p->pmgrid));
+  HIPCHK(hipEventRecord(ctx->ev[14], st));
+  GCHK(pm_deposit(ctx, p));
+  GCHK(pm_solve_and_interpolate(ctx, p));
   HIPCHK(hipEventRecord(ctx->ev[15], st));
   return GHIP_OK;
+}
+
+// rank-ordered sum of the all-gathered meshes (identical on every shard, whatever the transport)
+__global__ void k_pm_sum_meshes(size_t n3, int nranks, const double *__restrict__ all,
+                                double *__restrict__ rho)
+{
+  size_t g = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= n3)
+    return;
+  double s = 0;
+  for(int r = 0; r < nranks; r++)
+    s += all[(size_t) r * n3 + g];
+  rho[g] = s;
+}
+
+// GHIP_DD_PM (ghip_dd_begin / ghip_dd_step): phase 0 deposits and posts the all-gather of the meshes,
+// phase 1 adds them and solves
+int ghip_dd_pm_begin(ghip_ctx *ctx)
+{
+  GHIP_JOIN(ctx);
+  return pm_check(ctx, &ctx->dd.pm);
+}
+
+int ghip_dd_pm_step(ghip_ctx *ctx)
+{
+  DDState &D = ctx->dd;
+  const ghip_pm_params *p = &D.pm;
+  hipStream_t st = ctx->stream;
+  const size_t n3 = (size_t) p->pmgrid * p->pmgrid * p->pmgrid;
+  if(D.phase == 0)
+    {
+      GCHK(pm_prepare(ctx, p->pmgrid));
+      HIPCHK(hipEventRecord(ctx->ev[14], st));
+      GCHK(pm_deposit(ctx, p));
+      ghip_dd_set_allgather(D, ctx->pm_rho.p, n3 * sizeof(double), &D.pm_all);
+      D.phase = 1;
+      return 1;
+    }
+  if(D.phase == 1)
+    {
+      k_pm_sum_meshes<<<cdiv((long long) n3, 256), 256, 0, st>>>(n3, D.nranks, P<double>(D.pm_all),
+                                                                 P<double>(ctx->pm_rho));
+      HIPCHK(hipGetLastError());
+      GCHK(pm_solve_and_interpolate(ctx, p));
+      HIPCHK(hipEventRecord(ctx->ev[15], st));
+      D.op = 0;
+      return 0;
+    }
+  return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: the mesh force has no phase %d", D.phase);
 }
 
 void ghip_pm_release(ghip_ctx *ctx)

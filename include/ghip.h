@@ -382,7 +382,8 @@ int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p);
  * arrays, the victims' marks (P[].SwallowID, SphP[].i.Injected_BH_Energy) are resident.  Scalar
  * bookkeeping per sink (blackhole_accretion(), blackhole.c:133-300, 680-760), the conversion of a
  * flagged gas particle into a sink (sfr_eff.c:606-640, GSL stream) and DoCooling (cooling.c) stay
- * host code.  Single-GPU contexts only. ---- */
+ * host code.  On a multi-GPU shard the neighbour passes run through GHIP_DD_SINK_DENSITY /
+ * GHIP_DD_BH_EVALUATE / GHIP_DD_BH_SWALLOW below. ---- */
 typedef struct
 {
   double BoxSize;
@@ -459,6 +460,12 @@ typedef struct
 #define GHIP_DD_SINK_DENSITY 5   /* needs GHIP_DD_DENSITY of this step (the shard's gas tree) */
 #define GHIP_DD_BH_EVALUATE 6    /* needs GHIP_DD_GRAVITY of this step (the shard's gravity tree) */
 #define GHIP_DD_BH_SWALLOW 7
+/* pmforce_periodic on shards (params: ghip_pm_params): every shard deposits ITS particles on the full
+ * PMGRID^3 mesh, the meshes are all-gathered and added in rank order (8 PMGRID^3 bytes per shard:
+ * 16.8 MB at PMGRID = 128), then every shard transforms the identical mesh and interpolates the
+ * force for its own particles -- the reference's slab exchange (pm_periodic.c:263-450) with the
+ * transform replicated instead of distributed.  Pairs with GHIP_WALK_SHORTRANGE of GHIP_DD_GRAVITY. */
+#define GHIP_DD_PM 8
 
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],

@@ -447,6 +447,46 @@ def test_sharded_sph_variants(variant):
         S.close()
 
 
+@pytest.mark.parametrize("nshards,ng,pmgrid", [(3, 16, 32), (8, 32, 128)])
+def test_treepm_on_shards(nshards, ng, pmgrid):
+    """TreePM across shards (c3's force split on c4's decomposition): GHIP_DD_PM -- every shard
+    deposits its particles, the meshes are all-gathered and added in rank order, every shard solves
+    the identical mesh and interpolates for its own particles -- against the numpy restatement of
+    pmforce_periodic; the short-range walk on the same shards against the oracle's (counts exact);
+    and their sum against the exact periodic force (direct sum + Ewald) on a sample."""
+    B = bindings()
+    pr = Problem(ng=ng, gas=True, periodic=1)
+    n = pr.n
+    G = 43007.1
+    S = ShardSet(pr, nshards)
+    try:
+        asmth = 1.25 * pr.box / pmgrid
+        S.run.run(B.DD_PM, B.PmParams(pmgrid, pr.box, G, asmth))
+        got = S.get_field(B.F_GRAVPM)
+        want = O.pm_periodic(pr.ic["pos"], pr.ic["mass"], pr.box, G, pmgrid)
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() < 1e-11 * scale
+        info = S.each(lambda fp: fp.dd_info())
+        assert all(fp.stats()["ms_pm"] > 0 for fp in S.fp)
+        T = pr.oracle_tree()
+        tg = np.arange(n, dtype=np.int32)
+        old = np.zeros(n)
+        oacc, ocost = T.gravity(pr.o_grav(0.3, rcut=4.5 * asmth, asmth=asmth), tg, old, kind="shortrange")
+        S.run.gravity(pr.g_grav(0.3, 4.5 * asmth, asmth), B.WALK_SHORTRANGE)
+        assert np.array_equal(S.get_field(B.F_GRAVCOST), ocost)
+        assert relerr(S.get_field(B.F_GRAVACCEL), oacc) < TOL
+        if pmgrid == 128:
+            total = G * S.get_field(B.F_GRAVACCEL) + got
+            sample = np.sort(np.random.default_rng(1).choice(n, 128, replace=False)).astype(np.int32)
+            d = G * O.gravity_direct(pr.ic["pos"], pr.ic["mass"], pr.ic["type"], pr.force_soft, sample,
+                                     periodic=1, boxsize=pr.box, ewald_tab=O.ewald_table(pr.box))
+            err = np.linalg.norm(total[sample] - d, axis=1) / np.linalg.norm(d, axis=1)
+            assert np.median(err) < 0.01 and np.percentile(err, 95) < 0.05
+        del info
+    finally:
+        S.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_bench_ranks_share_one_gpu_through_the_host_transport(nranks):
     """The multi-process form of the domain-decomposed path, as the driver launches it
