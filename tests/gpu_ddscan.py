@@ -39,8 +39,18 @@ def main():
     B = bindings()
     pr = Problem(ng=ng, gas=True, periodic=1)
     base = None
+    balance = os.environ.get("DDSCAN_BALANCE", "0") == "1"
     for P in Ps:
-        S = ShardSet(pr, P)
+        work = None
+        if balance and P > 1:
+            # domain.c:378-384: cut the curve by cumulative (1 + GravCost) of a first step
+            S0 = ShardSet(pr, P)
+            run_op(S0, B.DD_GRAVITY, pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
+            S0.each(lambda fp: fp.gravity_finish(pr.G))
+            run_op(S0, B.DD_GRAVITY, pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+            work = 1.0 + S0.get_field(B.F_GRAVCOST).astype(np.float64)
+            S0.close()
+        S = ShardSet(pr, P, work=work)
         S.each(lambda fp: fp.dd_set_ghost_margin(2.0))
         # step 0: Barnes-Hut pass for OldAcc, density to converge h; then the measured step
         run_op(S, B.DD_GRAVITY, pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
