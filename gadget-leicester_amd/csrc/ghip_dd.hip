@@ -438,12 +438,15 @@ __device__ __forceinline__ double d_bcast(double v, int j)
 
 // One level of the top-down pass: a node some rank reaches is either left as it is for that rank
 // (pruned: sent as one element) or descended (its children become reachable).
-// One wavefront per 64 consecutive elements.  Lane-parallel: which of them are nodes of this level
+// One wavefront per LET_EPW consecutive elements (the candidates of a wavefront are tested one after
+// the other, so few per wavefront keep a level's launch short; all 64 lanes take part in every
+// test).  Lane-parallel: which of them are nodes of this level
 // that somebody reaches, and does the cell lie wholly inside this shard's key range.  Then, rank by
 // rank: lane l holds super-group l of that rank's table in registers, and the candidates that rank
 // reaches are tested one after the other against all 64 super-groups at once (and against the 16
 // groups of up to four hit super-groups at a time).  Finally every candidate lane publishes its own
 // result and marks its children.
+#define LET_EPW 16
 __global__ void __launch_bounds__(64)
 k_let_level(int nelem, int level, const int4 *__restrict__ lk, const double4 *__restrict__ xm,
             const double4 *__restrict__ cl, const double *__restrict__ aux,
@@ -451,11 +454,11 @@ k_let_level(int nelem, int level, const int4 *__restrict__ lk, const double4 *__
             unsigned long long *__restrict__ reach, unsigned long long *__restrict__ sendm)
 {
   const int lane = threadIdx.x;
-  const int e = blockIdx.x * 64 + lane;
+  const int e = blockIdx.x * LET_EPW + lane;
   bool cand = false;
   int4 me = make_int4(0, 0, 0, 0);
   unsigned long long r = 0;
-  if(e < nelem)
+  if(lane < LET_EPW && e < nelem)
     {
       me = lk[e];
       if(me.y == -(level + 1))
@@ -1006,7 +1009,7 @@ static int gravity_step(ghip_ctx *ctx)
                              *sendm = P<unsigned long long>(D.sendm);
           k_let_init<<<cdiv(t.nelem, 256), 256, 0, st>>>(t.nelem, all, reach, sendm);
           for(int L = 0; L <= t.maxlevel; L++)
-            k_let_level<<<cdiv(t.nelem, 64), 64, 0, st>>>(
+            k_let_level<<<cdiv(t.nelem, LET_EPW), 64, 0, st>>>(
               t.nelem, L, P<int4>(t.lk), P<double4>(t.xm), P<double4>(t.cl), P<double>(t.aux),
               P<unsigned long long>(t.skey), P<DDGroup>(D.grp_all), K, reach, sendm);
           k_let_single<<<1, 64, 0, st>>>(t.nelem, P<int4>(t.lk), reach, sendm);
