@@ -353,6 +353,9 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   HIPCHK(hipGetLastError());
   if(!walk_records)
     return GHIP_OK;
+  if((long long) t.nelem + 2 >= (1LL << 26))
+    return ghip_fail(ctx, GHIP_EINVAL, "the walk addresses its 64-byte element records by a 32-bit byte "
+                     "offset: %d elements are more than 2^26", t.nelem);
   GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkHot)));
   GCHK(ghip_ensure(ctx, t.mq2, (size_t) (t.nelem + 1) * sizeof(WalkCold)));
   k_fill_elems<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double4>(t.xm),

@@ -73,7 +73,10 @@ struct __attribute__((aligned(64))) WalkCold
   double spare[3];
 };
 
-typedef int v16i __attribute__((ext_vector_type(16)));
+// a 64-byte record in 16 consecutive SGPRs, as eight doubles: every double of a record is an
+// aligned register pair as it arrives (a record of sixteen ints would have to be re-assembled into
+// doubles with scalar shifts and ors)
+typedef double v16i __attribute__((ext_vector_type(8)));
 
 // two neighbouring entries of the Ewald table (8-byte aligned; the hardware takes 16-byte
 // global loads at any dword address)
@@ -88,55 +91,70 @@ __device__ __forceinline__ EwPair d_ldpair(const double *p)
 
 __device__ __forceinline__ double d_f64(const v16i &v, int i)
 {
-  return __hiloint2double(v[2 * i + 1], v[2 * i]);
+  return v[i];
+}
+// the two 32-bit halves of double i
+__device__ __forceinline__ int d_lo32(const v16i &v, int i)
+{
+  return __double2loint(v[i]);
+}
+__device__ __forceinline__ int d_hi32(const v16i &v, int i)
+{
+  return __double2hiint(v[i]);
 }
 
 // Scalar loads of 64-byte records (wave-uniform index).  Load and wait are ONE asm statement:
 // a scalar load writes its destination asynchronously, and between two asm statements the
 // register allocator would be free to copy or spill a destination that is still in flight.
-template <class T>
-__device__ __forceinline__ const T *d_uniform_ptr(const T *__restrict__ base, int e)
+// The address is the list's base (an SGPR pair for the whole kernel) plus a 32-bit byte offset
+// e * 64 in one SGPR -- the instruction adds them (and an immediate), where a 64-bit pointer per
+// record costs four scalar instructions: the walk issues more scalar than vector instructions,
+// and the scalar unit is the first to fill (ghip_build_segments refuses lists beyond 2^26
+// records).
+__device__ __forceinline__ unsigned int d_rec_off(int e)
 {
-  unsigned long long a = reinterpret_cast<unsigned long long>(base + e);
-  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int) a);
-  unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int) (a >> 32));
-  return reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+  return (unsigned int) __builtin_amdgcn_readfirstlane(e) << 6;
 }
 template <class T>
 __device__ __forceinline__ void d_load1(const T *__restrict__ base, int e, v16i &R)
 {
-  const T *p = d_uniform_ptr(base, e);
-  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(R) : "s"(p) : "memory");
+  const unsigned int off = d_rec_off(e);
+  asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(R) : "s"(base), "s"(off) : "memory");
 }
 // two records in flight together (the Ewald walk's two segment cursors)
 template <class T>
 __device__ __forceinline__ void d_load2(const T *__restrict__ base, int ea, v16i &A, int eb, v16i &B)
 {
-  const T *pa = d_uniform_ptr(base, ea), *pb = d_uniform_ptr(base, eb);
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+  const unsigned int oa = d_rec_off(ea), ob = d_rec_off(eb);
+  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(A), "=&s"(B)
-               : "s"(pa), "s"(pb)
+               : "s"(base), "s"(oa), "s"(ob)
                : "memory");
 }
-// Touch record `e` so that its cache line is on its way into the scalar cache: one dword into a
+// Touch a record so that its cache line is on its way into the scalar cache: one dword into a
 // scratch SGPR.  This is the one deliberately asynchronous load: the scratch register is an in/out
 // operand of every later wait (d_load1_touch, d_drain_touch), nothing else may use it in between,
 // and tests/test_abi_and_host.py checks the generated code for exactly that.
+// d_touch_next: the record after the one at byte offset `off` (immediate offset: no address arithmetic)
+template <class T>
+__device__ __forceinline__ void d_touch_next(const T *__restrict__ base, unsigned int off, int &scratch)
+{
+  asm volatile("s_load_dword %0, %1, %2 offset:0x40" : "=s"(scratch) : "s"(base), "s"(off) : "memory");
+}
 template <class T>
 __device__ __forceinline__ void d_touch(const T *__restrict__ base, int e, int &scratch)
 {
-  const T *p = d_uniform_ptr(base, e);
-  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(scratch) : "s"(p) : "memory");
+  const unsigned int off = d_rec_off(e);
+  asm volatile("s_load_dword %0, %1, %2" : "=s"(scratch) : "s"(base), "s"(off) : "memory");
 }
-// load record `e` and wait for it and for the outstanding touches
+// load the record at byte offset `off` and wait for it and for the outstanding touches
 template <class T>
-__device__ __forceinline__ void d_load1_touch(const T *__restrict__ base, int e, v16i &R, int &s1,
-                                              int &s2)
+__device__ __forceinline__ void d_load1_touch(const T *__restrict__ base, unsigned int off, v16i &R,
+                                              int &s1, int &s2)
 {
-  const T *p = d_uniform_ptr(base, e);
-  asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+  asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=s"(R), "+s"(s1), "+s"(s2)
-               : "s"(p)
+               : "s"(base), "s"(off)
                : "memory");
 }
 __device__ __forceinline__ void d_drain_touch(int &s1, int &s2)
@@ -323,7 +341,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
 {
   const double ex = d_f64(H, 0), ey = d_f64(H, 1), ez = d_f64(H, 2), mass = d_f64(H, 3);
   const double mlen2 = d_f64(H, 4), len2 = d_f64(H, 5);
-  const int skip = H[12], pidx = H[13];
+  const int skip = d_lo32(H, 6), pidx = d_hi32(H, 6);
   const double aux = d_f64(H, 7);
   const lmask act = D_BAL(e >= my_skip);
   int next;
@@ -331,9 +349,28 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   double dx = ex - W.pos_x, dy = ey - W.pos_y, dz = ez - W.pos_z;
   if(MODE == GHIP_WALK_EWALD || PERIODIC)
     {
-      dx = d_nearest1_masked(dx, p.boxsize, p.boxhalf);
-      dy = d_nearest1_masked(dy, p.boxsize, p.boxhalf);
-      dz = d_nearest1_masked(dz, p.boxsize, p.boxhalf);
+      // nearest image (forcetree.c:49): three compares into lane masks, ONE scalar test for "no lane
+      // on any axis" -- the common case -- and only otherwise the per-axis shifts under their masks
+      const lmask wx = D_BAL(fabs(dx) > p.boxhalf), wy = D_BAL(fabs(dy) > p.boxhalf),
+                  wz = D_BAL(fabs(dz) > p.boxhalf);
+      if((wx | wy | wz) != 0)
+        {
+          if(D_LANE(wx))
+            {
+              dx -= copysign(p.boxsize, dx);
+              asm volatile("" : "+v"(dx));
+            }
+          if(D_LANE(wy))
+            {
+              dy -= copysign(p.boxsize, dy);
+              asm volatile("" : "+v"(dy));
+            }
+          if(D_LANE(wz))
+            {
+              dz -= copysign(p.boxsize, dz);
+              asm volatile("" : "+v"(dz));
+            }
+        }
     }
   const double r2 = dx * dx + dy * dy + dz * dz;
   double h = W.h_i, h2 = W.h2;
@@ -376,7 +413,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
       //    0.6*len: |x - s| < (0.6 + 0.5)*sqrt(3)*len), tested conservatively with 4*len^2
       //    (formed exactly by adding 2 to the exponent, on the scalar unit)
       //  * the short-range cut-off pruning and the Ewald override
-      const double len2x4 = __hiloint2double(H[11] + 0x00200000, H[10]);
+      const double len2x4 = __hiloint2double(d_hi32(H, 5) + 0x00200000, d_lo32(H, 5));
       const lmask boxcand = far & D_BAL(r2 < len2x4);
       lmask cutcand = 0;
       if(MODE == GHIP_WALK_SHORTRANGE)
@@ -618,9 +655,10 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       while(liveA)
         {
           v16i HA;
-          d_load1_touch(hot, A.e, HA, t1, t2);
-          d_touch(hot, A.e + 1, t1);
-          d_touch(hot, HA[12], t2);
+          const unsigned int offA = d_rec_off(A.e);
+          d_load1_touch(hot, offA, HA, t1, t2);
+          d_touch_next(hot, offA, t1);
+          d_touch(hot, d_lo32(HA, 6), t2);
           steps++;
           A.e = __builtin_amdgcn_readfirstlane(
             d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
