@@ -494,11 +494,33 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
           // it came along) must never be opened -- the sender proved that no target here can.  If
           // one does, the locally essential tree was incomplete: hard error, not silently lost
           // mass.  (A cell of this shard's own holds >= 2 particles: its skip is >= e + 3.)
-          if(skip == next && d_walk_errw)
-            *(volatile int *) d_walk_errw = 1;
+          // (a real branch on the scalar compare first: the pointer is a global load, and a
+          // combined condition would wait for it at every opened node)
+          if(skip == next)
+            {
+              int *w = *(int *volatile *) &d_walk_errw;
+              if(w)
+                *(volatile int *) w = 1;
+            }
         }
     }
 
+  // Newtonian walk, nobody inside its softening length (the common case, one scalar test): the plain
+  // m / r^3 under ONE execution mask -- the general block below switches masks for the two branches
+  // of the softened kernel (forcetree.c:2143-2171)
+  if(OWNED && MODE == GHIP_WALK_NEWTON && (interact & D_BAL(r2 < h2)) == 0)
+    {
+      if(D_LANE(interact))
+        {
+          const double rinv = d_rsqrt(r2);
+          const double fac = mass * rinv * rinv * rinv;
+          W.acc_x += dx * fac;
+          W.acc_y += dy * fac;
+          W.acc_z += dz * fac;
+          W.nint += (mass > 0) ? 1 : 0;
+        }
+      return next;
+    }
   if(OWNED && D_LANE(interact))
     {
       if(MODE == GHIP_WALK_EWALD)
@@ -569,10 +591,10 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
 {
   while(c.kseg < sg.ns)
     {
-      const int s0 = sg.start[c.kseg];
-      c.s1 = sg.start[c.kseg + 1];
+      const int s0 = __builtin_amdgcn_readfirstlane(sg.start[c.kseg]);
+      c.s1 = __builtin_amdgcn_readfirstlane(sg.start[c.kseg + 1]);
       my_skip = valid ? 0 : 0x7fffffff;
-      const int na = sg.nanc[c.kseg];
+      const int na = __builtin_amdgcn_readfirstlane(sg.nanc[c.kseg]);
       for(int a = 0; a < na; a++)
         {
           int ea = __builtin_amdgcn_readfirstlane(sg.anc[c.kseg * GHIP_MAXANC + a]);
