@@ -332,7 +332,7 @@ typedef unsigned long long lmask;
 // One element of the list for all 64 lanes.  H = hot record (already in SGPRs).  OWNED = false
 // replays only the opening decision (ancestor of a segment).  Returns the next element index
 // (wave-uniform).  All 64 lanes are active here (lanes without a target carry my_skip = INT_MAX).
-template <int MODE, bool PERIODIC, bool UNEQUAL, bool OWNED>
+template <int MODE, bool PERIODIC, bool UNEQUAL, bool OWNED, bool REL>
 __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
                                               const WalkCold *__restrict__ cold, const GravK &p,
                                               const float *__restrict__ srtab,
@@ -393,11 +393,12 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
     {
       // first part of the criterion needs only the hot record (forcetree.c:2074-2091)
       lmask gt, rel;
-      if(p.theta == 0)
+      // (REL = "ErrTolTheta == 0": the kernel runs one of two copies of the traversal, so that the
+      // choice of the criterion costs no scalar instruction per element)
+      if(REL)
         {
           gt = D_BAL(mlen2 > r2 * r2 * W.aold);
           rel = ~0ull;
-          asm volatile("" : "+s"(gt));   // keep the two criteria in separate (uniform) branches
         }
       else
         {
@@ -581,7 +582,7 @@ struct SegCursor
 
 // enter segment `c.kseg`: replay the ancestors, position the cursor at the first element any lane
 // still needs.  Returns false when the slot has no segment left.
-template <int MODE, bool PERIODIC, bool UNEQUAL>
+template <int MODE, bool PERIODIC, bool UNEQUAL, bool REL>
 __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const WalkSeg &sg,
                                                 const WalkHot *__restrict__ hot,
                                                 const WalkCold *__restrict__ cold, const GravK &p,
@@ -600,7 +601,7 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
           int ea = __builtin_amdgcn_readfirstlane(sg.anc[c.kseg * GHIP_MAXANC + a]);
           v16i H;
           d_load1(hot, ea, H);
-          d_walk_element<MODE, PERIODIC, UNEQUAL, false>(ea, H, cold, p, srtab, ewtab, W, my_skip);
+          d_walk_element<MODE, PERIODIC, UNEQUAL, false, REL>(ea, H, cold, p, srtab, ewtab, W, my_skip);
           steps++;
         }
       int first = d_wave_min_i32(my_skip);   // every lane below an accepted ancestor: jump
@@ -610,6 +611,111 @@ __device__ __forceinline__ bool d_enter_segment(SegCursor &c, int stride, const 
       c.kseg += stride;
     }
   return false;
+}
+
+// the traversal of one wavefront: its segments of the element list for its bucket
+template <int MODE, bool PERIODIC, bool UNEQUAL, bool REL>
+__device__ __forceinline__ void d_walk_run(const WalkSeg &sg, int sub, const WalkHot *__restrict__ hot,
+                                           const WalkCold *__restrict__ cold, const GravK &p,
+                                           const float *__restrict__ srtab,
+                                           const double *__restrict__ ewtab, bool valid, WalkLane &W,
+                                           unsigned int &steps)
+{
+  if(MODE != GHIP_WALK_EWALD)
+    {
+      // this wavefront owns segments sub, sub+S, sub+2S, ...  (advancing two segments at once was
+      // measured for the Newtonian walk: no gain, +9 VGPRs -- that walk is issue-bound)
+      SegCursor A;
+      int skipA = 0;
+      A.kseg = sub;
+      const int stride = sg.nsub;
+      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(A, stride, sg, hot, cold, p, srtab,
+                                                            ewtab, valid, W, skipA, steps);
+      // Both possible successors of an element -- e+1 (descend / next particle) and its skip
+      // link -- are touched as soon as its record has arrived, so the next step's 64-byte load
+      // finds its line in the scalar cache instead of paying the L2 latency of the pointer
+      // chase.  (the list carries one padding record: e+1 and skip are always readable)
+      int t1 = 0, t2 = 0;
+      while(liveA)
+        {
+          v16i HA;
+          const unsigned int offA = d_rec_off(A.e);
+          d_load1_touch(hot, offA, HA, t1, t2);
+          d_touch_next(hot, offA, t1);
+          d_touch(hot, d_lo32(HA, 6), t2);
+          steps++;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true, REL>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          if(A.e >= A.s1)
+            {
+              // drain the touches first: their scratch registers must not be live while a load
+              // into them is in flight across code the register allocator is free to spill in
+              d_drain_touch(t1, t2);
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(A, stride, sg, hot, cold, p, srtab,
+                                                               ewtab, valid, W, skipA, steps);
+            }
+        }
+      d_drain_touch(t1, t2);
+    }
+  else
+    {
+      // Ewald walk: bound by the table gathers (12 x 16 B per lane and interaction through the
+      // vector-memory path).  Two of the wavefront's segments advance together (slot A: sub,
+      // sub+2S, ...; slot B: sub+S, sub+3S, ...) so that two elements' gathers are in flight.
+      SegCursor A, B;
+      int skipA = 0, skipB = 0;
+      A.kseg = sub;
+      B.kseg = sub + sg.nsub;
+      const int stride = 2 * sg.nsub;
+      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                   W, skipA, steps);
+      bool liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
+                                                   W, skipB, steps);
+      while(liveA && liveB)
+        {
+          v16i HA, HB;
+          d_load2(hot, A.e, HA, B.e, HB);
+          steps += 2;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true, REL>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          B.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true, REL>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
+          if(A.e >= A.s1)
+            {
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(A, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipA, steps);
+            }
+          if(B.e >= B.s1)
+            {
+              B.kseg += stride;
+              liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(B, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipB, steps);
+            }
+        }
+      if(liveB)
+        {
+          A = B;
+          skipA = skipB;
+          liveA = true;
+        }
+      while(liveA)
+        {
+          v16i HA;
+          d_load1(hot, A.e, HA);
+          steps++;
+          A.e = __builtin_amdgcn_readfirstlane(
+            d_walk_element<MODE, PERIODIC, UNEQUAL, true, REL>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
+          if(A.e >= A.s1)
+            {
+              A.kseg += stride;
+              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL, REL>(A, stride, sg, hot, cold, p, srtab, ewtab,
+                                                      valid, W, skipA, steps);
+            }
+        }
+    }
+
 }
 
 // partial results: [nsub][nt] per component.
@@ -659,100 +765,11 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   W.nint = 0;
   unsigned int steps = 0;
 
-  if(MODE != GHIP_WALK_EWALD)
-    {
-      // this wavefront owns segments sub, sub+S, sub+2S, ...  (advancing two segments at once was
-      // measured for the Newtonian walk: no gain, +9 VGPRs -- that walk is issue-bound)
-      SegCursor A;
-      int skipA = 0;
-      A.kseg = sub;
-      const int stride = sg.nsub;
-      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab,
-                                                            ewtab, valid, W, skipA, steps);
-      // Both possible successors of an element -- e+1 (descend / next particle) and its skip
-      // link -- are touched as soon as its record has arrived, so the next step's 64-byte load
-      // finds its line in the scalar cache instead of paying the L2 latency of the pointer
-      // chase.  (the list carries one padding record: e+1 and skip are always readable)
-      int t1 = 0, t2 = 0;
-      while(liveA)
-        {
-          v16i HA;
-          const unsigned int offA = d_rec_off(A.e);
-          d_load1_touch(hot, offA, HA, t1, t2);
-          d_touch_next(hot, offA, t1);
-          d_touch(hot, d_lo32(HA, 6), t2);
-          steps++;
-          A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
-          if(A.e >= A.s1)
-            {
-              // drain the touches first: their scratch registers must not be live while a load
-              // into them is in flight across code the register allocator is free to spill in
-              d_drain_touch(t1, t2);
-              A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab,
-                                                               ewtab, valid, W, skipA, steps);
-            }
-        }
-      d_drain_touch(t1, t2);
-    }
+  // two copies of the traversal, one per opening criterion (a uniform choice: no divergence)
+  if(p.theta == 0)
+    d_walk_run<MODE, PERIODIC, UNEQUAL, true>(sg, sub, hot, cold, p, srtab, ewtab, valid, W, steps);
   else
-    {
-      // Ewald walk: bound by the table gathers (12 x 16 B per lane and interaction through the
-      // vector-memory path).  Two of the wavefront's segments advance together (slot A: sub,
-      // sub+2S, ...; slot B: sub+S, sub+3S, ...) so that two elements' gathers are in flight.
-      SegCursor A, B;
-      int skipA = 0, skipB = 0;
-      A.kseg = sub;
-      B.kseg = sub + sg.nsub;
-      const int stride = 2 * sg.nsub;
-      bool liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                   W, skipA, steps);
-      bool liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL>(B, stride, sg, hot, cold, p, srtab, ewtab, valid,
-                                                   W, skipB, steps);
-      while(liveA && liveB)
-        {
-          v16i HA, HB;
-          d_load2(hot, A.e, HA, B.e, HB);
-          steps += 2;
-          A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
-          B.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(B.e, HB, cold, p, srtab, ewtab, W, skipB));
-          if(A.e >= A.s1)
-            {
-              A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
-                                                      valid, W, skipA, steps);
-            }
-          if(B.e >= B.s1)
-            {
-              B.kseg += stride;
-              liveB = d_enter_segment<MODE, PERIODIC, UNEQUAL>(B, stride, sg, hot, cold, p, srtab, ewtab,
-                                                      valid, W, skipB, steps);
-            }
-        }
-      if(liveB)
-        {
-          A = B;
-          skipA = skipB;
-          liveA = true;
-        }
-      while(liveA)
-        {
-          v16i HA;
-          d_load1(hot, A.e, HA);
-          steps++;
-          A.e = __builtin_amdgcn_readfirstlane(
-            d_walk_element<MODE, PERIODIC, UNEQUAL, true>(A.e, HA, cold, p, srtab, ewtab, W, skipA));
-          if(A.e >= A.s1)
-            {
-              A.kseg += stride;
-              liveA = d_enter_segment<MODE, PERIODIC, UNEQUAL>(A, stride, sg, hot, cold, p, srtab, ewtab,
-                                                      valid, W, skipA, steps);
-            }
-        }
-    }
+    d_walk_run<MODE, PERIODIC, UNEQUAL, false>(sg, sub, hot, cold, p, srtab, ewtab, valid, W, steps);
 
   if(valid)
     {

@@ -216,19 +216,28 @@ def test_walk_touch_registers_stay_reserved_inside_the_loop():
                    if "#ASMSTART" in body[i - 1] and re.search(r"\ss_load_dword\s+s\d+,", body[i])]
         if not touches:
             continue
-        regs = {int(re.search(r"s_load_dword\s+s(\d+),", body[i]).group(1)) for i in touches}
-        # the window in which a touch may be in flight: from the touch to the drain that precedes
-        # the segment switch (laid out after the step body; marked in the asm text)
-        drain = next(i for i in range(touches[-1], len(body)) if "drain-touches" in body[i])
-        for i in range(touches[0], drain):
-            ins = body[i].split(";")[0]
-            if i in touches or not ins.strip():
+        # the windows in which a touch may be in flight: from the first touch after a drain to the
+        # next drain (the drain that precedes the segment switch is laid out after the step body and
+        # marked in the asm text).  A kernel holds one traversal loop per opening criterion, each
+        # with its own scratch registers.
+        drains = [i for i in range(len(body)) if "drain-touches" in body[i]]
+        assert drains and drains[-1] > touches[-1]
+        prev = -1
+        for d in drains:
+            mine = [i for i in touches if prev < i < d]
+            prev = d
+            if not mine:
                 continue
-            for m in re.finditer(r"\bs(\d+)\b", ins):
-                assert int(m.group(1)) not in regs, ins
-            for m in re.finditer(r"s\[(\d+):(\d+)\]", ins):
-                lo, hi = int(m.group(1)), int(m.group(2))
-                assert not any(lo <= r <= hi for r in regs), ins
+            regs = {int(re.search(r"s_load_dword\s+s(\d+),", body[i]).group(1)) for i in mine}
+            for i in range(mine[0], d):
+                ins = body[i].split(";")[0]
+                if i in mine or not ins.strip():
+                    continue
+                for m in re.finditer(r"\bs(\d+)\b", ins):
+                    assert int(m.group(1)) not in regs, ins
+                for m in re.finditer(r"s\[(\d+):(\d+)\]", ins):
+                    lo, hi = int(m.group(1)), int(m.group(2))
+                    assert not any(lo <= r <= hi for r in regs), ins
         checked += 1
     assert checked >= 4      # the Newtonian and short-range walks, periodic or not
 
