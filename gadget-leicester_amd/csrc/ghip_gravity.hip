@@ -525,15 +525,15 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
     P<float>(ctx->srtab), P<double>((UNEQ) && MODE == GHIP_WALK_EWALD ? ctx->ewbrick : ctx->ewtab),  \
     pb.ax, pb.ay, pb.az, pb.cost, counter, plan)
   // The Ewald walk has no softening rule; its UNEQUAL instantiation is the variant that reads the
-  // brick-tiled table.  Alone the walk is bound by the L2 requests of its gathers and the bricks cut
-  // them (6.3 -> 4.65 ms at c2); next to a chip-filling Newtonian walk it has one or two wavefronts
-  // per SIMD, is bound by the latency of its dependent chain, and the longer index arithmetic of the
-  // bricks costs more than the fewer lines gain (step 10.58 -> 10.86 ms): the pair keeps plain rows.
+  // brick-tiled table (the default; GHIP_EW_BRICK=0 selects the plain rows).  Alone the walk is bound
+  // by the L2 requests of its gathers and the bricks cut them (6.3 -> 4.5 ms at c2); inside a pair
+  // the bricks pay since the walks' scalar-instruction diet made the pair vector-issue bound
+  // (step 9.90 -> 9.56 ms together with the leaner look-up; before that diet the pair was bound by
+  // scalar issue and latency and the bricks' longer index arithmetic lost: DESIGN.md 4.3).
   static int brick_env = -2;
   if(brick_env == -2)
     brick_env = getenv("GHIP_EW_BRICK") ? atoi(getenv("GHIP_EW_BRICK")) : -1;
-  const bool in_full_pair = stream != ctx->stream && nbuckets >= cap_min;
-  const bool brick = brick_env >= 0 ? brick_env != 0 : !in_full_pair;
+  const bool brick = brick_env >= 0 ? brick_env != 0 : true;
   const bool uneq = (MODE == GHIP_WALK_EWALD) ? brick : (bool) k.unequal;
   if(k.periodic && uneq)
     GHIP_LAUNCH_WALK(true, true);

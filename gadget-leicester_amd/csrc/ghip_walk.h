@@ -203,22 +203,11 @@ __device__ __forceinline__ void d_ewald_interp(const double *__restrict__ tab, d
                                                double &fy, double &fz)
 {
   const int E1 = GHIP_EN + 1;
-  double sx = -1, sy = -1, sz = -1;
-  if(dx < 0)
-    {
-      dx = -dx;
-      sx = +1;
-    }
-  if(dy < 0)
-    {
-      dy = -dy;
-      sy = +1;
-    }
-  if(dz < 0)
-    {
-      dz = -dz;
-      sz = +1;
-    }
+  // |d| for the look-up (a free source modifier), the sign put back at the end: -1 for d >= 0
+  const double sx = dx < 0 ? 1.0 : -1.0, sy = dy < 0 ? 1.0 : -1.0, sz = dz < 0 ? 1.0 : -1.0;
+  dx = fabs(dx);
+  dy = fabs(dy);
+  dz = fabs(dz);
   double u = dx * fac_intp;
   int i = (int) u;
   if(i >= GHIP_EN)
@@ -245,15 +234,21 @@ __device__ __forceinline__ void d_ewald_interp(const double *__restrict__ tab, d
   EwPair x00, x01, x10, x11, y00, y01, y10, y11, z00, z01, z10, z11;
   if(!BRICK)
     {
-      const double *bx = tab + ((size_t) i * E1 + j) * E1 + k;
-      const double *by = tab + ((size_t) j * E1 + i) * E1 + k;
-      const double *bz = tab + ((size_t) k * E1 + j) * E1 + i;
-      x00 = d_ldpair(bx), x01 = d_ldpair(bx + E1), x10 = d_ldpair(bx + E1 * E1),
-      x11 = d_ldpair(bx + E1 * E1 + E1);
-      y00 = d_ldpair(by), y01 = d_ldpair(by + E1), y10 = d_ldpair(by + E1 * E1),
-      y11 = d_ldpair(by + E1 * E1 + E1);
-      z00 = d_ldpair(bz), z01 = d_ldpair(bz + E1), z10 = d_ldpair(bz + E1 * E1),
-      z11 = d_ldpair(bz + E1 * E1 + E1);
+      // 32-bit byte offsets from the (wave-uniform) table pointer: the loads take them as they are
+      // (scalar base + vector offset), the row +1 in the second index through the instruction's
+      // immediate offset
+      const unsigned int ui = (unsigned int) i, uj = (unsigned int) j, uk = (unsigned int) k;
+      const unsigned int R1 = E1 * 8u, R2 = E1 * E1 * 8u;
+      const unsigned int ox = (ui * E1 + uj) * R1 + uk * 8u;
+      const unsigned int oy = (uj * E1 + ui) * R1 + uk * 8u;
+      const unsigned int oz = (uk * E1 + uj) * R1 + ui * 8u;
+      const unsigned int ox2 = ox + R2, oy2 = oy + R2, oz2 = oz + R2;
+      const char *tb = reinterpret_cast<const char *>(tab);
+#define EW_LD(off, imm) d_ldpair(reinterpret_cast<const double *>(tb + (size_t) (off) + (imm)))
+      x00 = EW_LD(ox, 0), x01 = EW_LD(ox, R1), x10 = EW_LD(ox2, 0), x11 = EW_LD(ox2, R1);
+      y00 = EW_LD(oy, 0), y01 = EW_LD(oy, R1), y10 = EW_LD(oy2, 0), y11 = EW_LD(oy2, R1);
+      z00 = EW_LD(oz, 0), z01 = EW_LD(oz, R1), z10 = EW_LD(oz2, 0), z11 = EW_LD(oz2, R1);
+#undef EW_LD
     }
   else
     {
