@@ -961,8 +961,28 @@ struct HydAcc
 struct HydTgt
 {
   double px, py, pz, vx, vy, vz, h_i, h_i2, mass, rho, f1, p_over_rho2_i, soundspeed_i, timestep;
+  double hinv_i, hinv4_i;   // 1 / h_i and its fourth power, as d_hydro_pair used to form them per pair
 };
 
+// What depends on the candidate alone (hydra.c:1321-1326, 1440-1448), formed ONCE per candidate --
+// by the lane that stages it, or on the spot for a single-particle element -- instead of by every
+// lane of every pair: p_over_rho2_j = P_j / rho_j^2, soundspeed_j = sqrt(GAMMA p_over_rho2_j rho_j),
+// 1 / h_j.  Same operations in the same order as the per-pair form: identical numbers.
+struct HydCand
+{
+  double p_over_rho2, soundspeed, hinv;
+};
+__device__ __forceinline__ HydCand d_hydro_candidate(double pres_j, double rho_j, double h_j)
+{
+  HydCand C;
+  C.p_over_rho2 = pres_j / (rho_j * rho_j);
+  C.soundspeed = sqrt(GAMMA * C.p_over_rho2 * rho_j);
+  C.hinv = 1.0 / h_j;
+  return C;
+}
+
+// r8: (x,y,z,m,vx,vy,vz,h) of the candidate; q8: (p_over_rho2, rho, dhsml factor, divv, curl, timestep,
+// soundspeed, 1/h) -- slots 0, 6, 7 as d_hydro_candidate leaves them
 __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8, bool valid,
                                              const HydTgt &T, const HydK &K, const BoxK b,
                                              HydAcc &A)
@@ -975,28 +995,25 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
   if(valid && (r2 < T.h_i2 || r2 < h_j * h_j) && r2 > 0)
     {
       A.np++;
-      const double pres_j = q8[0], rho_j = q8[1], dhf_j = q8[2], divv_j = q8[3], curl_j = q8[4],
-                   ts_j = q8[5];
-      double r = sqrt(r2);
-      double p_over_rho2_j = pres_j / (rho_j * rho_j);
-      double soundspeed_j = sqrt(GAMMA * p_over_rho2_j * rho_j);
+      double p_over_rho2_j = q8[0];
+      const double rho_j = q8[1], dhf_j = q8[2], divv_j = q8[3], curl_j = q8[4], ts_j = q8[5];
+      const double soundspeed_j = q8[6], hinv_j = q8[7];
+      const double r = sqrt(r2);
+      const double rinv = 1.0 / r;   // (the reference divides by r three times: one reciprocal here)
       double dvx = T.vx - jvx, dvy = T.vy - jvy, dvz = T.vz - jvz;
       double vdotr = dx * dvx + dy * dvy + dz * dvz;
       double vdotr2 = K.comoving ? vdotr + K.hubble_a2 * r2 : vdotr;
       double dwk_i = 0, dwk_j = 0;
       if(r2 < T.h_i2)
         {
-          double hinv = 1.0 / T.h_i;
-          double hinv4 = hinv * hinv * hinv * hinv;
-          double u = r * hinv;
-          dwk_i = (u < 0.5) ? hinv4 * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4)
-                            : hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
+          const double u = r * T.hinv_i;
+          dwk_i = (u < 0.5) ? T.hinv4_i * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4)
+                            : T.hinv4_i * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
         }
       if(r2 < h_j * h_j)
         {
-          double hinv = 1.0 / h_j;
-          double hinv4 = hinv * hinv * hinv * hinv;
-          double u = r * hinv;
+          const double hinv4 = hinv_j * hinv_j * hinv_j * hinv_j;
+          const double u = r * hinv_j;
           dwk_j = (u < 0.5) ? hinv4 * u * (KERNEL_COEFF_3 * u - KERNEL_COEFF_4)
                             : hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
         }
@@ -1007,12 +1024,12 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
       if(vdotr2 < 0)
         {
           // hydra.c:1512-1594
-          double mu_ij = K.fac_mu * vdotr2 / r;
+          double mu_ij = K.fac_mu * vdotr2 * rinv;
           vsig -= 3 * mu_ij;
           if(vsig > A.maxsig)
             A.maxsig = vsig;
           double rho_ij = 0.5 * (T.rho + rho_j);
-          double f2 = fabs(divv_j) / (fabs(divv_j) + curl_j + 0.0001 * soundspeed_j / K.fac_mu / h_j);
+          double f2 = fabs(divv_j) / (fabs(divv_j) + curl_j + 0.0001 * soundspeed_j / K.fac_mu * hinv_j);
           visc = 0.25 * K.visc_const * vsig * (-mu_ij) / rho_ij * (T.f1 + f2);
           double tmax = (T.timestep > ts_j) ? T.timestep : ts_j;
           double dt = 2 * tmax * K.timebase;
@@ -1025,8 +1042,8 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
             }
         }
       p_over_rho2_j *= dhf_j;
-      double hfc_visc = 0.5 * mass_j * visc * (dwk_i + dwk_j) / r;
-      double hfc = hfc_visc + mass_j * (T.p_over_rho2_i * dwk_i + p_over_rho2_j * dwk_j) / r;
+      double hfc_visc = 0.5 * mass_j * visc * (dwk_i + dwk_j) * rinv;
+      double hfc = hfc_visc + mass_j * (T.p_over_rho2_i * dwk_i + p_over_rho2_j * dwk_j) * rinv;
       A.ax += -hfc * dx;
       A.ay += -hfc * dy;
       A.az += -hfc * dz;
@@ -1054,7 +1071,7 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
   const int ti = bucket * TG + tl;
   const bool valid = ti < nt;
   const int s = valid ? tgt[ti] : 0;
-  HydTgt T = {0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 0};
+  HydTgt T = {0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 0, 1, 1};
   if(valid)
     {
       const double *r8 = gp + (size_t) 8 * s;
@@ -1068,6 +1085,8 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
       T.vz = r8[6];
       T.h_i = r8[7];
       T.h_i2 = T.h_i * T.h_i;
+      T.hinv_i = 1.0 / T.h_i;
+      T.hinv4_i = T.hinv_i * T.hinv_i * T.hinv_i * T.hinv_i;
       double pres = q8[0];
       T.rho = q8[1];
       double dhf = q8[2], divv = q8[3], curl = q8[4];
@@ -1091,7 +1110,12 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
       if(pidx >= 0)
         {
           if((batch++ % nsub) == sub)
-            d_hydro_pair(gp + (size_t) 8 * pidx, gq + (size_t) 8 * pidx, valid && cs == 0, T, K, b, A);
+            {
+              const double *qs = gq + (size_t) 8 * pidx;
+              const HydCand C = d_hydro_candidate(qs[0], qs[1], gp[(size_t) 8 * pidx + 7]);
+              const double q8[8] = {C.p_over_rho2, qs[1], qs[2], qs[3], qs[4], qs[5], C.soundspeed, C.hinv};
+              d_hydro_pair(gp + (size_t) 8 * pidx, q8, valid && cs == 0, T, K, b, A);
+            }
           e = e + 1;
         }
       else
@@ -1118,10 +1142,15 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
                               reinterpret_cast<const double4 *>(gq + (size_t) 8 * (pstart + r0 + lane));
                             c0 = s0[0];
                             c1 = s0[1];
+                            double4 q0 = s1[0], q1 = s1[1];   // (P, rho, f, divv) (curl, timestep, -, -)
+                            const HydCand C = d_hydro_candidate(q0.x, q0.y, c1.w);
+                            q0.x = C.p_over_rho2;
+                            q1.z = C.soundspeed;
+                            q1.w = C.hinv;
                             sh[lane][0] = c0;
                             sh[lane][1] = c1;
-                            sh[lane][2] = s1[0];
-                            sh[lane][3] = s1[1];
+                            sh[lane][2] = q0;
+                            sh[lane][3] = q1;
                           }
                         // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
                         unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c1.w, b);
