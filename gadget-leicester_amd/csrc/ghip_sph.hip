@@ -970,19 +970,32 @@ struct HydTgt
 // 1 / h_j.  Same operations in the same order as the per-pair form: identical numbers.
 struct HydCand
 {
-  double p_over_rho2, soundspeed, hinv;
+  double p_over_rho2, soundspeed, hinv, f2;
 };
-__device__ __forceinline__ HydCand d_hydro_candidate(double pres_j, double rho_j, double h_j)
+__device__ __forceinline__ HydCand d_hydro_candidate(double pres_j, double rho_j, double h_j,
+                                                     double divv_j, double curl_j, double fac_mu)
 {
   HydCand C;
   C.p_over_rho2 = pres_j / (rho_j * rho_j);
   C.soundspeed = sqrt(GAMMA * C.p_over_rho2 * rho_j);
   C.hinv = 1.0 / h_j;
+  // the Balsara factor of the candidate (hydra.c:1548-1551)
+  C.f2 = fabs(divv_j) / (fabs(divv_j) + curl_j + 0.0001 * C.soundspeed / fac_mu * C.hinv);
   return C;
 }
 
-// r8: (x,y,z,m,vx,vy,vz,h) of the candidate; q8: (p_over_rho2, rho, dhsml factor, divv, curl, timestep,
-// soundspeed, 1/h) -- slots 0, 6, 7 as d_hydro_candidate leaves them
+// 1/sqrt(x) to full fp64 precision from the hardware seed (as the gravity walk's d_rsqrt)
+__device__ __forceinline__ double d_rsqrt_sph(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double t = x * y;
+  double e = fma(-t, y, 1.0);
+  double p = fma(0.375, e, 0.5);
+  return fma(y * e, p, y);
+}
+
+// r8: (x,y,z,m,vx,vy,vz,h) of the candidate; q8: (p_over_rho2, rho, dhsml factor, f2, -, timestep,
+// soundspeed, 1/h) -- slots 0, 3, 6, 7 as d_hydro_candidate leaves them
 __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8, bool valid,
                                              const HydTgt &T, const HydK &K, const BoxK b,
                                              HydAcc &A)
@@ -996,10 +1009,11 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
     {
       A.np++;
       double p_over_rho2_j = q8[0];
-      const double rho_j = q8[1], dhf_j = q8[2], divv_j = q8[3], curl_j = q8[4], ts_j = q8[5];
+      const double rho_j = q8[1], dhf_j = q8[2], f2 = q8[3], ts_j = q8[5];
       const double soundspeed_j = q8[6], hinv_j = q8[7];
-      const double r = sqrt(r2);
-      const double rinv = 1.0 / r;   // (the reference divides by r three times: one reciprocal here)
+      // (the reference takes sqrt(r2) and divides by r three times: one reciprocal square root here)
+      const double rinv = d_rsqrt_sph(r2);
+      const double r = r2 * rinv;
       double dvx = T.vx - jvx, dvy = T.vy - jvy, dvz = T.vz - jvz;
       double vdotr = dx * dvx + dy * dvy + dz * dvz;
       double vdotr2 = K.comoving ? vdotr + K.hubble_a2 * r2 : vdotr;
@@ -1029,7 +1043,6 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
           if(vsig > A.maxsig)
             A.maxsig = vsig;
           double rho_ij = 0.5 * (T.rho + rho_j);
-          double f2 = fabs(divv_j) / (fabs(divv_j) + curl_j + 0.0001 * soundspeed_j / K.fac_mu * hinv_j);
           visc = 0.25 * K.visc_const * vsig * (-mu_ij) / rho_ij * (T.f1 + f2);
           double tmax = (T.timestep > ts_j) ? T.timestep : ts_j;
           double dt = 2 * tmax * K.timebase;
@@ -1112,8 +1125,9 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
           if((batch++ % nsub) == sub)
             {
               const double *qs = gq + (size_t) 8 * pidx;
-              const HydCand C = d_hydro_candidate(qs[0], qs[1], gp[(size_t) 8 * pidx + 7]);
-              const double q8[8] = {C.p_over_rho2, qs[1], qs[2], qs[3], qs[4], qs[5], C.soundspeed, C.hinv};
+              const HydCand C = d_hydro_candidate(qs[0], qs[1], gp[(size_t) 8 * pidx + 7], qs[3], qs[4],
+                                                  K.fac_mu);
+              const double q8[8] = {C.p_over_rho2, qs[1], qs[2], C.f2, 0.0, qs[5], C.soundspeed, C.hinv};
               d_hydro_pair(gp + (size_t) 8 * pidx, q8, valid && cs == 0, T, K, b, A);
             }
           e = e + 1;
@@ -1143,8 +1157,9 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
                             c0 = s0[0];
                             c1 = s0[1];
                             double4 q0 = s1[0], q1 = s1[1];   // (P, rho, f, divv) (curl, timestep, -, -)
-                            const HydCand C = d_hydro_candidate(q0.x, q0.y, c1.w);
+                            const HydCand C = d_hydro_candidate(q0.x, q0.y, c1.w, q0.w, q1.x, K.fac_mu);
                             q0.x = C.p_over_rho2;
+                            q0.w = C.f2;
                             q1.z = C.soundspeed;
                             q1.w = C.hinv;
                             sh[lane][0] = c0;
