@@ -130,6 +130,16 @@ __device__ __forceinline__ unsigned long long d_cull_batch(const BucketBox &B, b
 // ---------------------------------------------------------------------------------------------
 // density
 // ---------------------------------------------------------------------------------------------
+// 1/sqrt(x) to full fp64 precision from the hardware seed (as the gravity walk's d_rsqrt)
+__device__ __forceinline__ double d_rsqrt_sph(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double t = x * y;
+  double e = fma(-t, y, 1.0);
+  double p = fma(0.375, e, 0.5);
+  return fma(y * e, p, y);
+}
+
 struct DensAcc
 {
   double rho, wnum, dhsml, divv, rx, ry, rz;
@@ -141,7 +151,8 @@ struct DensAcc
 __device__ __forceinline__ void d_density_pair(const double *r8, bool valid,
                                                double px, double py, double pz, double vx,
                                                double vy, double vz, double h2, double hinv,
-                                               double hinv3, double hinv4, const BoxK b, DensAcc &A)
+                                               double hinv3, double hinv4, double h3, const BoxK b,
+                                               DensAcc &A)
 {
   const double jx = r8[0], jy = r8[1], jz = r8[2], mass_j = r8[3];
   const double jvx = r8[4], jvy = r8[5], jvz = r8[6];
@@ -150,7 +161,10 @@ __device__ __forceinline__ void d_density_pair(const double *r8, bool valid,
   if(valid && r2 < h2)
     {
       A.nn++;
-      double r = sqrt(r2);
+      // r and 1/r from one reciprocal square root (the target itself is among the candidates: r = 0);
+      // the reference's sqrt and its divisions by r and by hinv3 become multiplications
+      const double rinv = r2 > 0 ? d_rsqrt_sph(r2) : 0.0;
+      const double r = r2 * rinv;
       double u = r * hinv, wk, dwk;
       if(u < 0.5)
         {
@@ -163,11 +177,11 @@ __device__ __forceinline__ void d_density_pair(const double *r8, bool valid,
           dwk = hinv4 * KERNEL_COEFF_6 * (1.0 - u) * (1.0 - u);
         }
       A.rho += mass_j * wk;
-      A.wnum += NORM_COEFF * wk / hinv3;
+      A.wnum += NORM_COEFF * wk * h3;
       A.dhsml += -mass_j * (NUMDIMS * hinv * wk + u * dwk);
       if(r > 0)
         {
-          double fac = mass_j * dwk / r;
+          double fac = mass_j * dwk * rinv;
           double dvx = vx - jvx, dvy = vy - jvy, dvz = vz - jvz;
           A.divv += -fac * (dx * dvx + dy * dvy + dz * dvz);
           A.rx += fac * (dz * dvy - dy * dvz);
@@ -289,7 +303,7 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
       h = hcur[s];
     }
   const double h2 = h * h, hinv = 1.0 / h;
-  const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv;
+  const double hinv3 = hinv * hinv * hinv, hinv4 = hinv3 * hinv, h3 = h * h * h;
   DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
   const BucketBox BB = d_bucket_box(valid, px, py, pz, h, b);
 
@@ -304,7 +318,7 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
         {
           if((batch++ % nsub) == sub)
             d_density_pair(gp + (size_t) 8 * pidx, valid && cs == 0, px, py, pz, vx, vy, vz, h2, hinv,
-                           hinv3, hinv4, b, A);
+                           hinv3, hinv4, h3, b, A);
           e = e + 1;
         }
       else
@@ -336,7 +350,7 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
                             const int j = d_next_candidates<CS>(live, cs);
                             d_density_pair(reinterpret_cast<const double *>(&sh[j < 0 ? 0 : j][0]),
                                            valid && j >= 0, px, py, pz, vx, vy, vz, h2, hinv, hinv3,
-                                           hinv4, b, A);
+                                           hinv4, h3, b, A);
                           }
                       }
                   e = skip;
@@ -984,15 +998,6 @@ __device__ __forceinline__ HydCand d_hydro_candidate(double pres_j, double rho_j
   return C;
 }
 
-// 1/sqrt(x) to full fp64 precision from the hardware seed (as the gravity walk's d_rsqrt)
-__device__ __forceinline__ double d_rsqrt_sph(double x)
-{
-  double y = __builtin_amdgcn_rsq(x);
-  double t = x * y;
-  double e = fma(-t, y, 1.0);
-  double p = fma(0.375, e, 0.5);
-  return fma(y * e, p, y);
-}
 
 // r8: (x,y,z,m,vx,vy,vz,h) of the candidate; q8: (p_over_rho2, rho, dhsml factor, f2, -, timestep,
 // soundspeed, 1/h) -- slots 0, 3, 6, 7 as d_hydro_candidate leaves them
