@@ -50,8 +50,8 @@ BIN = 20                        # its time bin: Timebase_interval = DT_STEP / 2^
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ng", type=int, default=64, help="particles per dimension per species")
     ap.add_argument("--mode", choices=["dd", "replicated"], default="dd",
                     help="N > 1: domain decomposition (default) or replicated sources")
