@@ -106,6 +106,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # (the host driver of this pool supports dmabuf IPC only: RCCL's peer buffers need this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
