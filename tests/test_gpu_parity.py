@@ -724,6 +724,37 @@ def test_overlap_sph_sequence_gives_the_same_records():
         assert np.array_equal(res[0][k], res[1][k]), k
 
 
+def test_overlap_sph_on_a_substep_falls_back_to_per_call_results():
+    """overlap_sph with only part of the particles active (a sub-step): gravity_tree() then returns
+    with its results in P[] as without the flag (the deferral needs everybody active), and the
+    sequence gives the same records as the plain one."""
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    pr = Problem(ng=10, gas=True, periodic=1)
+    act = np.sort(np.random.default_rng(4).choice(pr.n, pr.n // 3, replace=False)).astype(np.int32)
+    res = []
+    for overlap in (0, 1):
+        host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap)
+        L = host.L
+        L.gravity_tree()
+        L.density()
+        L.force_update_hmax()
+        L.hydro_force()
+        host.set_active(act)
+        host.All.ErrTolTheta = 0
+        P["GravAccel"][:] = 0
+        L.gravity_tree()
+        assert np.abs(P["GravAccel"][act]).max() > 0          # delivered by the call itself
+        L.density()
+        L.force_update_hmax()
+        L.hydro_force()
+        assert host.endrun_codes == []
+        res.append({k: P[k].copy() for k in ("GravAccel", "OldAcc", "GravCost")} |
+                   {k: S[k].copy() for k in ("Density", "Hsml", "HydroAccel", "DtEntropy")})
+        host.close()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_compute_accelerations_sequence_on_aos_records():
     """gravity_tree() x2, density(), force_update_hmax(), hydro_force() exactly as accel.c:61-106
     calls them at Ti_Current == 0, on P[]/SphP[] records."""
