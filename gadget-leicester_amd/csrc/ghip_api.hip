@@ -469,7 +469,7 @@ __global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, in
   do                                                                                          \
     {                                                                                         \
       if((off) >= 0 && (cnt) > 0)                                                             \
-        k_unpack_f64<<<cdiv((long long) (cnt), 256), 256, 0, st>>>(                           \
+        k_unpack_f64<<<cdiv((long long) (cnt), ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(         \
           (size_t) (cnt), (const char *) (img), (stride), (off), (ncomp), P<double>(ctx->f[fld])); \
     }                                                                                         \
   while(0)
@@ -483,32 +483,16 @@ __global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, in
     }                                                                                         \
   while(0)
 
-extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, const ghip_layout *lay,
-                               int numpart, int ngas)
+// the P[] block: copy + unpack of the per-particle fields
+static int upload_p_block(ghip_ctx *ctx, const void *Pp, const ghip_layout *lay)
 {
-  if(ctx)
-    GHIP_JOIN(ctx);
-  if(!ctx || !lay || numpart < 0 || ngas < 0 || ngas > numpart || (numpart > 0 && !Pp) ||
-     (ngas > 0 && !Sp))
-    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad arguments");
-  if(lay->p_stride <= 0 || (ngas > 0 && lay->s_stride <= 0))
-    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad strides");
-  if((lay->p_hsml >= 0) == (lay->s_hsml >= 0) && ngas > 0)
-    return ghip_fail(ctx, GHIP_EINVAL,
-                     "ghip_upload_aos: exactly one of p_hsml / s_hsml must be set (PPP macro)");
-  GCHK(ghip_set_counts(ctx, numpart, ngas));
   hipStream_t st = ctx->stream;
-  size_t n = (size_t) numpart, ng = (size_t) ngas;
+  const size_t n = (size_t) ctx->n;
   if(n == 0)
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, ctx->aosP, n * lay->p_stride));
   HIPCHK(hipMemcpyAsync(ctx->aosP.p, Pp, n * lay->p_stride, hipMemcpyHostToDevice, st));
-  if(ng > 0)
-    {
-      GCHK(ghip_ensure(ctx, ctx->aosS, ng * lay->s_stride));
-      HIPCHK(hipMemcpyAsync(ctx->aosS.p, Sp, ng * lay->s_stride, hipMemcpyHostToDevice, st));
-    }
-  const void *ip = ctx->aosP.p, *is = ctx->aosS.p;
+  const void *ip = ctx->aosP.p;
   UNPACK64(n, ip, lay->p_stride, lay->p_pos, 3, GHIP_F_POS);
   UNPACK64(n, ip, lay->p_stride, lay->p_vel, 3, GHIP_F_VEL);
   UNPACK64(n, ip, lay->p_stride, lay->p_mass, 1, GHIP_F_MASS);
@@ -529,25 +513,101 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
   UNPACK64(n, ip, lay->p_stride, lay->p_gravpm, 3, GHIP_F_GRAVPM);
   if(lay->p_hsml >= 0)
     UNPACK64(n, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
-  if(ng > 0)
-    {
-      if(lay->s_hsml >= 0)
-        UNPACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);  // first ngas entries
-      UNPACK64(ng, is, lay->s_stride, lay->s_velpred, 3, GHIP_F_VELPRED);
-      UNPACK64(ng, is, lay->s_stride, lay->s_entropy, 1, GHIP_F_ENTROPY);
-      UNPACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
-      UNPACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
-      UNPACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
-      UNPACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
-      UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
-      UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
-      UNPACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
-      UNPACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
-    }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
+  return GHIP_OK;
+}
+
+// the SphP[] block: copy + unpack of the per-gas-particle fields.  The unpack kernels may run
+// underneath a gravity pair in flight: one-wavefront workgroups then (ghip_wg)
+static int upload_s_block(ghip_ctx *ctx, const void *Sp, const ghip_layout *lay)
+{
+  hipStream_t st = ctx->stream;
+  const size_t ng = (size_t) ctx->ngas;
+  if(ng == 0)
+    return GHIP_OK;
+  GCHK(ghip_ensure(ctx, ctx->aosS, ng * lay->s_stride));
+  HIPCHK(hipMemcpyAsync(ctx->aosS.p, Sp, ng * lay->s_stride, hipMemcpyHostToDevice, st));
+  const void *is = ctx->aosS.p;
+  if(lay->s_hsml >= 0)
+    UNPACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);  // first ngas entries
+  UNPACK64(ng, is, lay->s_stride, lay->s_velpred, 3, GHIP_F_VELPRED);
+  UNPACK64(ng, is, lay->s_stride, lay->s_entropy, 1, GHIP_F_ENTROPY);
+  UNPACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
+  UNPACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
+  UNPACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
+  UNPACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
+  UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
+  UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
+  UNPACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
+  UNPACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+static int check_upload_args(ghip_ctx *ctx, const void *Pp, const void *Sp, const ghip_layout *lay,
+                             int numpart, int ngas, bool need_s)
+{
+  if(!ctx || !lay || numpart < 0 || ngas < 0 || ngas > numpart || (numpart > 0 && !Pp) ||
+     (need_s && ngas > 0 && !Sp))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad arguments");
+  if(lay->p_stride <= 0 || (ngas > 0 && lay->s_stride <= 0))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos: bad strides");
+  if((lay->p_hsml >= 0) == (lay->s_hsml >= 0) && ngas > 0)
+    return ghip_fail(ctx, GHIP_EINVAL,
+                     "ghip_upload_aos: exactly one of p_hsml / s_hsml must be set (PPP macro)");
+  return GHIP_OK;
+}
+
+extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, const ghip_layout *lay,
+                               int numpart, int ngas)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  GCHK(check_upload_args(ctx, Pp, Sp, lay, numpart, ngas, true));
+  GCHK(ghip_set_counts(ctx, numpart, ngas));
+  if(numpart == 0)
+    return GHIP_OK;
+  GCHK(upload_p_block(ctx, Pp, lay));
+  GCHK(upload_s_block(ctx, Sp, lay));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->gt.built = false;
   ctx->st.built = false;
+  ctx->gas_wait_upload = false;
+  return GHIP_OK;
+}
+
+// The same in two calls, for a host that starts gravity before the gas data are across: the P[]
+// block (everything the gravity tree and its walks read -- unless the smoothing lengths, which
+// ADAPTIVE_GRAVSOFT_FORGAS makes softenings, live in SphP[]) ...
+extern "C" int ghip_upload_aos_particles(ghip_ctx *ctx, const void *Pp, const ghip_layout *lay,
+                                         int numpart, int ngas)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  GCHK(check_upload_args(ctx, Pp, nullptr, lay, numpart, ngas, false));
+  if(ctx->adaptive_gravsoft && lay->p_hsml < 0 && ngas > 0)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos_particles: with adaptive gravitational softening "
+                     "the smoothing lengths of SphP[] are needed first: use ghip_upload_aos");
+  GCHK(ghip_set_counts(ctx, numpart, ngas));
+  if(numpart == 0)
+    return GHIP_OK;
+  GCHK(upload_p_block(ctx, Pp, lay));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->gt.built = false;
+  ctx->st.built = false;
+  ctx->gas_wait_upload = ngas > 0;   // (whatever joins in between must leave the gas tree deferred)
+  return GHIP_OK;
+}
+
+// ... and the SphP[] block, which may follow while a gravity pair is in flight (it is not waited
+// for): before the first SPH call of the step.
+extern "C" int ghip_upload_aos_gas(ghip_ctx *ctx, const void *Sp, const ghip_layout *lay)
+{
+  if(!ctx || !lay || (ctx->ngas > 0 && (!Sp || lay->s_stride <= 0)))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos_gas: bad arguments");
+  GCHK(upload_s_block(ctx, Sp, lay));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->gas_wait_upload = false;
   return GHIP_OK;
 }
 

@@ -243,6 +243,8 @@ struct ghip_ctx
   // the second half of the gas tree build (elements, moments, SphNode records, gas records) is
   // deferred to the first call that needs it, so that it runs underneath a gravity pair
   bool gas_pending = false;
+  bool gas_wait_upload = false;   // ghip_upload_aos_particles done, ghip_upload_aos_gas not yet: the
+                                   // deferred gas-tree work must not run on stale SphP fields
   int gas_hinfo[3] = {0, 0, 0};
   hipEvent_t evx[4];               // pair ordering: inputs ready / Newton combined / Ewald combined /
                                    // Ewald walk kernel done (ghip_hydro waits for it)

@@ -717,6 +717,9 @@ __global__ void __launch_bounds__(64) k_sel_scatter(int n, const int *__restrict
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 {
   GCHK(ghip_finish_gas_tree(ctx));
+  if(ctx->gas_wait_upload)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: ghip_upload_aos_particles was not followed by "
+                     "ghip_upload_aos_gas");
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: call ghip_tree_build first");
   GCHK(ghip_build_target_lists(ctx));

@@ -1231,7 +1231,7 @@ int ghip_dd_refresh_ghosts(ghip_ctx *ctx)
 
 int ghip_finish_gas_tree(ghip_ctx *ctx)
 {
-  if(!ctx->gas_pending)
+  if(!ctx->gas_pending || ctx->gas_wait_upload)
     return GHIP_OK;
   ctx->gas_pending = false;
   const int n = ctx->n, ng = ctx->ngas;

@@ -53,6 +53,7 @@ static int DeviceFresh = 0;      /* device copy of P/SphP matches the host array
 static int TreeOnDevice = 0;
 static int Phase = 0;            /* 1 after gravity_tree(), 2 after density(): accel.c:61-106 order */
 static int GravPending = 0;      /* overlap_sph: walks in flight, post-pass + download still to do */
+static int GasPending = 0;       /* overlap_sph: P[] is on the device, SphP[] still to follow */
 static int GravPendingActive = 0;
 static int *ActiveBuf = NULL;
 static int ActiveCap = 0;
@@ -151,6 +152,7 @@ void gadget_force_finalize(void)
   TreeOnDevice = 0;
   Phase = 0;
   GravPending = 0;
+  GasPending = 0;
   /* the host's arrays are the host's: forget them, a later init must set them again */
   Nodes_base = Nodes = NULL;
   Extnodes_base = Extnodes = NULL;
@@ -417,15 +419,37 @@ static int need_ctx(const char *who)
   return -1;
 }
 
-static int upload_particles(void)
+/* split != 0 (gravity_tree with overlap_sph): only the P[] block now, the SphP[] block once the walks
+ * are in flight (upload_gas_if_pending) */
+static int upload_particles(int split)
 {
   ghip_layout lay;
   gadget_force_layout(&lay);
-  if(chk(ghip_upload_aos(Ctx, P, SphP, &lay, NumPart, N_gas), "ghip_upload_aos"))
-    return -1;
+  if(split && N_gas > 0 && lay.p_hsml < 0)
+    {
+      if(chk(ghip_upload_aos_particles(Ctx, P, &lay, NumPart, N_gas), "ghip_upload_aos_particles"))
+        return -1;
+      GasPending = 1;
+    }
+  else
+    {
+      if(chk(ghip_upload_aos(Ctx, P, SphP, &lay, NumPart, N_gas), "ghip_upload_aos"))
+        return -1;
+      GasPending = 0;
+    }
   DeviceFresh = 1;
   TreeOnDevice = 0;
   return 0;
+}
+
+static int upload_gas_if_pending(void)
+{
+  if(!GasPending)
+    return 0;
+  GasPending = 0;
+  ghip_layout lay;
+  gadget_force_layout(&lay);
+  return chk(ghip_upload_aos_gas(Ctx, SphP, &lay), "ghip_upload_aos_gas") ? -1 : 0;
 }
 
 /* the active list as the reference threads it (run.c:300-320) */
@@ -545,7 +569,7 @@ int force_treebuild(int npart, void *mp)
     return -1;
   double t0 = wallclock();
   if(!DeviceFresh)
-    if(upload_particles())
+    if(upload_particles(0))
       return -1;
   if(DomainLen <= 0)
     domain_findExtent();
@@ -572,11 +596,11 @@ void ewald_init(void)
   chk(ghip_ewald_init(Ctx, All.BoxSize), "ghip_ewald_init");
 }
 
-static int ensure_tree(void)
+static int ensure_tree_split(int split)
 {
   if(!DeviceFresh)
     {
-      if(upload_particles())
+      if(upload_particles(split))
         return -1;
     }
   if(TreeReconstructFlag || !TreeOnDevice)
@@ -586,6 +610,13 @@ static int ensure_tree(void)
       TreeReconstructFlag = 0;
     }
   return 0;
+}
+
+static int ensure_tree(void)
+{
+  if(ensure_tree_split(0))
+    return -1;
+  return upload_gas_if_pending();   /* (a caller other than gravity_tree needs the gas data now) */
 }
 
 /* the tail of gravity_tree(): post-pass on the device, results into P[] (download != 0: by a
@@ -646,10 +677,12 @@ void gravity_tree(void)
    * reference reuses a drifted tree on sub-steps (forcetree.c:1356-1452); this path rebuilds. */
   DeviceFresh = 0;
   TreeOnDevice = 0;
-  if(ensure_tree())
-    return;
   int nact = collect_active(0);
   if(nact < 0)
+    return;
+  /* overlap_sph: everything the walks read is in P[]; SphP[] follows once they are in flight */
+  const int defer = Cfg.overlap_sph && Cfg.periodic && !Cfg.pmgrid && N_gas > 0 && nact == NumPart;
+  if(ensure_tree_split(defer))
     return;
   if(chk(ghip_set_active(Ctx, nact == NumPart ? NULL : ActiveBuf, nact == NumPart ? 0 : nact),
          "ghip_set_active"))
@@ -669,11 +702,15 @@ void gravity_tree(void)
    * follow in hydro_force() / gadget_force_flush() */
   if(Cfg.overlap_sph && walk == GHIP_WALK_NEWTON_EWALD && N_gas > 0 && nact == NumPart)
     {
+      if(upload_gas_if_pending())
+        return;
       GravPending = 1;
       Phase = 1;
       CPU_Step_Treewalk += wallclock() - t0;
       return;
     }
+  if(upload_gas_if_pending())
+    return;
   if(gravity_complete(1))
     return;
   Phase = 1;
@@ -852,7 +889,7 @@ void find_dt_displacement_constraint(double hfac)
     return;
   if(need_ctx("find_dt_displacement_constraint"))
     return;
-  if(!DeviceFresh && upload_particles())
+  if(!DeviceFresh && upload_particles(0))
     return;
   double v_sum[6], min_mass[6];
   long long count_sum[6];
@@ -936,7 +973,7 @@ void advance_and_find_timesteps(void)
     }
   /* the accelerations of this step are on the device (Phase 0 after hydro_force); velocities and
    * entropies are the host's: make the device image current */
-  if(!DeviceFresh && upload_particles())
+  if(!DeviceFresh && upload_particles(0))
     return;
   if(Flag_FullStep || dt_displacement == 0)
     find_dt_displacement_constraint(hubble_a * atime * atime);

@@ -252,6 +252,13 @@ int ghip_get_field(ghip_ctx *ctx, int field, void *host);
  * (results are packed into the device image of the records, then one D2H per block) */
 int ghip_upload_aos(ghip_ctx *ctx, const void *P, const void *SphP, const ghip_layout *lay,
                     int numpart, int ngas);
+/* The same in two calls, for a host that starts the gravity walks before the gas data are across:
+ * ghip_upload_aos_particles moves the P[] block (all the gravity tree and its walks read, unless
+ * ADAPTIVE_GRAVSOFT_FORGAS needs smoothing lengths that live in SphP[]: refused then), and
+ * ghip_upload_aos_gas the SphP[] block -- it does not wait for a GHIP_WALK_NEWTON_EWALD pair in
+ * flight and must precede the first SPH call of the step. */
+int ghip_upload_aos_particles(ghip_ctx *ctx, const void *P, const ghip_layout *lay, int numpart, int ngas);
+int ghip_upload_aos_gas(ghip_ctx *ctx, const void *SphP, const ghip_layout *lay);
 int ghip_download_aos(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay,
                       int want_gravity, int want_density, int want_hydro);
 
