@@ -1065,7 +1065,7 @@ static int density_step(ghip_ctx *ctx)
   DDState &D = ctx->dd;
   hipStream_t st = ctx->stream;
   const int P_ = D.nranks;
-  const int n = ctx->n, ng = ctx->ngas;
+  const int ng = ctx->ngas;
   if(D.phase == 0)
     {
       // groups of the gas targets (bounding box, padded search radius) from the curve order of the
