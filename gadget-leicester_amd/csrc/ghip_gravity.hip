@@ -321,16 +321,24 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
       if(v >= 1 && v <= 4096)
         ns = v;
     }
-  // three tables: fine (ns), mid (ns/2), coarse (ns/4).  The fine one serves small launches (one
-  // rank's share of a multi-GPU run: many wavefronts per bucket), the mid one a full-size
-  // Newtonian walk (enough buckets to fill the chip, so fewer ancestor replays win: 7.0 -> 6.8 ms
-  // at c2), the coarse one the Ewald walk, which visits ~6x fewer elements per bucket.
+  // three tables: fine (ns), mid (48), coarse (16).  The fine one serves small launches (one rank's
+  // share of a multi-GPU run: many wavefronts per bucket), the mid one a full-size Newtonian walk
+  // (enough buckets to fill the chip, so fewer ancestor replays win), the coarse one the Ewald walk,
+  // which visits ~6x fewer elements per bucket.  48 / 16 were measured with the round-2 kernels (a
+  // cheaper element visit makes the ancestor replays of a segment entry relatively dearer): step at
+  // c2 9.19 -> 8.58 ms, at c4's size on one GPU 81.7 -> 76.1 ms, against ns/2 = 128 and ns/4 = 64.
   SegTables T;
   T.ntab = 3;
   int so = 0, no = 0, total = 0;
   for(int j = 0; j < 3; j++)
     {
-      int v = ns >> j;
+      int v = j == 0 ? ns : (j == 1 ? 48 : 16);
+      if(j == 1 && getenv("GHIP_WALK_SEG_MID"))
+        v = atoi(getenv("GHIP_WALK_SEG_MID"));
+      if(j == 2 && getenv("GHIP_WALK_SEG_COARSE"))
+        v = atoi(getenv("GHIP_WALK_SEG_COARSE"));
+      if(v > ns)
+        v = ns;
       T.ns[j] = v < 1 ? 1 : v;
       T.soff[j] = so;
       T.noff[j] = no;
@@ -395,7 +403,9 @@ static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, boo
       if(getenv("GHIP_WALK_MID_MIN"))
         mid_min = atoi(getenv("GHIP_WALK_MID_MIN"));
     }
-  int table = ewald ? 2 : (*nbuckets >= mid_min ? 1 : 0);
+  // (a small launch -- one rank's share -- needs more wavefronts per bucket than the coarser table has
+  // segments: one table finer for both walks)
+  int table = ewald ? (*nbuckets >= mid_min ? 2 : 1) : (*nbuckets >= mid_min ? 1 : 0);
   return ghip_walk_layout(t, sg, table);
 }
 
