@@ -399,7 +399,7 @@ static int walk_layout(const TreeDev &t, int nt, WalkSeg &sg, int *nbuckets, boo
   static int mid_min = -1;
   if(mid_min < 0)
     {
-      mid_min = 6144;   // buckets from which a Newtonian walk uses the mid table
+      mid_min = 3072;   // buckets from which the walks use the coarser tables (c2: 2 shards yes, 4 no)
       if(getenv("GHIP_WALK_MID_MIN"))
         mid_min = atoi(getenv("GHIP_WALK_MID_MIN"));
     }
