@@ -321,18 +321,24 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
       if(v >= 1 && v <= 4096)
         ns = v;
     }
-  // three tables: fine (ns), mid (48), coarse (16).  The fine one serves small launches (one rank's
+  // three tables: fine (ns), mid (48, or 96), coarse (16, or 32).  The fine one serves small launches (one rank's
   // share of a multi-GPU run: many wavefronts per bucket), the mid one a full-size Newtonian walk
   // (enough buckets to fill the chip, so fewer ancestor replays win), the coarse one the Ewald walk,
   // which visits ~6x fewer elements per bucket.  48 / 16 were measured with the round-2 kernels (a
   // cheaper element visit makes the ancestor replays of a segment entry relatively dearer): step at
   // c2 9.19 -> 8.58 ms, at c4's size on one GPU 81.7 -> 76.1 ms, against ns/2 = 128 and ns/4 = 64.
+  // A full-size shard of a larger box (c4 cut in 8: 8192 buckets each over a merged tree) is the one
+  // case measured that wants them finer: its heaviest buckets need more wavefronts than 48 segments
+  // allow (slowest shard's pair 12.9 ms with 48 / 16, 11.4 ms with 96 / 32; c2 cut in 2 -- 4096
+  // buckets each -- keeps 48 / 16: 5.17 against 5.40 ms).
+  const bool big_shard = ctx->dd.on && ctx->n >= 6144 * 64;
+  const int mid = big_shard ? 96 : 48, coarse = big_shard ? 32 : 16;
   SegTables T;
   T.ntab = 3;
   int so = 0, no = 0, total = 0;
   for(int j = 0; j < 3; j++)
     {
-      int v = j == 0 ? ns : (j == 1 ? 48 : 16);
+      int v = j == 0 ? ns : (j == 1 ? mid : coarse);
       if(j == 1 && getenv("GHIP_WALK_SEG_MID"))
         v = atoi(getenv("GHIP_WALK_SEG_MID"));
       if(j == 2 && getenv("GHIP_WALK_SEG_COARSE"))
