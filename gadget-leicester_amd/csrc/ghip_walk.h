@@ -173,6 +173,19 @@ __device__ __forceinline__ double d_rsqrt(double x)
   return fma(y * e, p, y);
 }
 
+// m / r^3 for the unsoftened interaction: y0 = v_rsq_f64(x), e = 1 - x*y0^2,
+// m*y^3 = m*y0^3 * (1 + 3e/2 + 15e^2/8 + O(e^3))   -- the same third-order step as d_rsqrt, cubed (7
+// operations where d_rsqrt and three multiplications take 8)
+__device__ __forceinline__ double d_mass_over_r3(double mass, double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double y2 = y * y;
+  double e = fma(-x, y2, 1.0);
+  double p = fma(1.875, e, 1.5);
+  double c = (mass * y) * y2;
+  return fma(c * e, p, c);
+}
+
 // softened monopole kernel, forcetree.c:2143-2171.  r2 >= h^2: m / r^3 through d_rsqrt.
 __device__ __forceinline__ double d_grav_fac(double mass, double r2, double h, double h2,
                                              double &r_out)
@@ -508,8 +521,7 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
     {
       if(D_LANE(interact))
         {
-          const double rinv = d_rsqrt(r2);
-          const double fac = mass * rinv * rinv * rinv;
+          const double fac = d_mass_over_r3(mass, r2);
           W.acc_x += dx * fac;
           W.acc_y += dy * fac;
           W.acc_z += dz * fac;
