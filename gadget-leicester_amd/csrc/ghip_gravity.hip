@@ -498,6 +498,8 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, i
   plan.woff = P<int>(b_woff);
   plan.nsub = P<int>(b_nsub);
   plan.steps_out = out;
+  plan.started = nullptr;
+  plan.started_at = 0;
   return GHIP_OK;
 }
 
@@ -520,6 +522,16 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
     }
   int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
+  WalkPlan pl = plan;
+  if(pl.started)
+    {
+      static double frac = -1;
+      if(frac < 0)
+        frac = getenv("GHIP_HYDRO_TRIGGER_AT") ? atof(getenv("GHIP_HYDRO_TRIGGER_AT")) : 1.0;
+      pl.started_at = (int) (frac * (blocks - 1));
+      if(pl.started_at > blocks - 1 || pl.started_at < 0)
+        pl.started_at = blocks - 1;
+    }
   // In a pair the Newtonian walk must leave room for the Ewald walk: at its full 8 wavefronts per
   // SIMD it owns the whole register file and the two kernels merely follow each other.  8 KB of
   // (unused) dynamic LDS per one-wavefront workgroup caps it at 20 per CU = 5 per SIMD, which
@@ -539,7 +551,7 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
     P<float>(ctx->srtab), P<double>((UNEQ) && MODE == GHIP_WALK_EWALD ? ctx->ewbrick : ctx->ewtab),  \
-    pb.ax, pb.ay, pb.az, pb.cost, counter, plan)
+    pb.ax, pb.ay, pb.az, pb.cost, counter, pl)
   // The Ewald walk has no softening rule; its UNEQUAL instantiation is the variant that reads the
   // brick-tiled table (the default; GHIP_EW_BRICK=0 selects the plain rows).  Alone the walk is bound
   // by the L2 requests of its gathers and the bricks cut them (6.3 -> 4.5 ms at c2); inside a pair
@@ -686,6 +698,11 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   HIPCHK(hipStreamWaitEvent(sN, ctx->evx[0], 0));
   HIPCHK(hipStreamWaitEvent(sE, ctx->evx[0], 0));
   GCHK(run_walk(ctx, A, nt, tgt, sN));
+  // (the word the hydro kernel's start waits for, see k_grav_walk: a stale 1 from the previous pair
+  // would only let hydro start early, never hold it back)
+  unsigned int *started = reinterpret_cast<unsigned int *>(P<unsigned long long>(ctx->counters) + 20);
+  HIPCHK(hipMemsetAsync(started, 0, 4, sE));
+  E.plan.started = started;
   GCHK(run_walk(ctx, E, nt, tgt, sE));
   HIPCHK(hipEventRecord(ctx->evx[3], sE));   // the Ewald walk's wavefront slots are free from here on
   GCHK(combine_walk(ctx, A, nt, tgt, sN));
@@ -694,6 +711,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   GCHK(combine_walk(ctx, E, nt, tgt, sE));
   HIPCHK(hipEventRecord(ctx->evx[2], sE));
   ctx->grav_pending = true;
+  ctx->pair_started = started;
   return GHIP_OK;
 }
 

@@ -240,6 +240,7 @@ struct ghip_ctx
   hipStream_t stream3 = nullptr;   // ... and its Newtonian walk here, so the main stream stays free
   bool adaptive_gravsoft = false;   // ADAPTIVE_GRAVSOFT_FORGAS: gas softening = Hsml (ghip_set_adaptive_gravsoft)
   bool grav_pending = false;       // a pair is in flight; evx[2] marks its end (see ghip_join)
+  unsigned int *pair_started = nullptr;   // device word: the pair's Ewald walk has dispatched its last workgroup
   // the second half of the gas tree build (elements, moments, SphNode records, gas records) is
   // deferred to the first call that needs it, so that it runs underneath a gravity pair
   bool gas_pending = false;

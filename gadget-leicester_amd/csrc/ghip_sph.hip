@@ -1271,8 +1271,20 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   // Underneath a gravity pair the hydro kernel (128 VGPRs) only fits where an Ewald wavefront would
   // sit, and while both walks run it slows them by more than it gains (11.4 vs 11.2 ms per step at
   // c2): it starts when the Ewald walk has drained and fills the tail of the Newtonian walk instead.
+  // "Drained" is taken one wavefront generation early: the walk sets a word when its LAST workgroup
+  // starts, and the stream waits for that word -- from then on the slots the Ewald walk gives back stay
+  // free, and hydro's wavefronts move in while the last Ewald ones finish (GHIP_HYDRO_TRIGGER=drain:
+  // the kernel's end event instead).
   if(ctx->grav_pending && !getenv("GHIP_HYDRO_EARLY"))
-    HIPCHK(hipStreamWaitEvent(st, ctx->evx[3], 0));
+    {
+      static int drain = -1;
+      if(drain < 0)
+        drain = getenv("GHIP_HYDRO_TRIGGER") && !strcmp(getenv("GHIP_HYDRO_TRIGGER"), "drain");
+      if(drain || !ctx->pair_started)
+        HIPCHK(hipStreamWaitEvent(st, ctx->evx[3], 0));
+      else
+        HIPCHK(hipStreamWaitValue32(st, ctx->pair_started, 1, hipStreamWaitValueGte, 0xffffffffu));
+    }
   HIPCHK(hipEventRecord(ctx->ev[10], st));
   const int tgw = ghip_sph_tg();
   const int nbk = (nt + tgw - 1) / tgw;

@@ -578,6 +578,8 @@ struct WalkPlan
   const int *__restrict__ woff;          // [nbuckets] first wavefront of the bucket
   const int *__restrict__ nsub;          // [nbuckets] wavefronts sharing the bucket
   unsigned int *__restrict__ steps_out;  // [nbuckets] elements visited (summed over wavefronts)
+  unsigned int *started;                 // != nullptr: set to 1 when workgroup started_at of the grid starts
+  int started_at;
 };
 
 // cursor over the segments one wavefront owns through one of its two slots
@@ -740,6 +742,11 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
             int *__restrict__ pcost, unsigned long long *__restrict__ counter, WalkPlan plan)
 {
   const int lane = threadIdx.x & 63;
+  // "every workgroup of this grid has been dispatched": from here on the kernel only drains, and the
+  // wavefront slots it gives back stay free -- the main stream's hydro kernel waits for this word
+  // (hipStreamWaitValue32 in ghip_hydro) instead of for the kernel's end
+  if(plan.started && blockIdx.x == plan.started_at && threadIdx.x == 0)
+    __hip_atomic_store(plan.started, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   const int per_xcd = gridDim.x >> 3;
   const int lblock = p.xcd_remap ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane((lblock * (int) blockDim.x + threadIdx.x) >> 6);
