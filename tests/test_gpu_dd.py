@@ -518,3 +518,30 @@ def test_bench_ranks_share_one_gpu_through_the_host_transport(nranks):
     x = out["exchange_per_step_rank0"]
     assert x["bytes_sent_tree_nodes"] > 0 and x["bytes_sent_ghosts"] > 0
     assert out["work_per_step_rank0"]["grav_interactions"] > 0
+
+
+def test_hydro_release_variants_do_the_same_work():
+    """When the hydro kernel is let go underneath a gravity pair is scheduling only: on the word the
+    Ewald walk sets when its last workgroup starts (default, hipStreamWaitValue32), on the walk's end
+    event (GHIP_HYDRO_TRIGGER=drain) or right away (GHIP_HYDRO_EARLY=1).  The switches are read once
+    per process, so each variant is one short bench run; the steps' interaction, neighbour and pair
+    counts must be identical and every run must finish."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = []
+    for extra in ({}, {"GHIP_HYDRO_TRIGGER": "drain"}, {"GHIP_HYDRO_EARLY": "1"}):
+        env = dict(os.environ, **extra)
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--ng", "24",
+               "--no-dropin", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        w = json.loads(lines[0])["work_per_step_rank0"]
+        work.append({k: w[k] for k in ("grav_interactions", "ewald_interactions", "dens_neighbours",
+                                       "hydro_pairs")})
+    assert work[0]["hydro_pairs"] > 0 and work[0]["ewald_interactions"] > 0
+    assert work[1] == work[0] and work[2] == work[0]
