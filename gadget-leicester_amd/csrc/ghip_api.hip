@@ -219,7 +219,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
                   &ctx->plan_wave, &ctx->plan_steps[0][0], &ctx->plan_steps[0][1],
                   &ctx->plan_steps[1][0], &ctx->plan_steps[1][1], &ctx->plan_steps[2][0],
                   &ctx->plan_steps[2][1], &ctx->tax2, &ctx->tay2, &ctx->taz2, &ctx->tcost2,
-                  &ctx->plan_nsub2, &ctx->plan_woff2, &ctx->plan_wave2, &ctx->cubtmp2,
+                  &ctx->plan_nsub2, &ctx->plan_woff2, &ctx->plan_wave2, &ctx->cubtmp2, &ctx->cubtmp3,
                   &ctx->bh_swallow, &ctx->bh_injected};
   for(DevBuf *b : bs)
     free_buf(*b);

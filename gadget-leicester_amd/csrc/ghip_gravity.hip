@@ -445,7 +445,8 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, i
 {
   hipStream_t st = on ? on : ctx->stream;
   DevBuf &b_nsub = slot ? ctx->plan_nsub2 : ctx->plan_nsub, &b_woff = slot ? ctx->plan_woff2 : ctx->plan_woff,
-         &b_wave = slot ? ctx->plan_wave2 : ctx->plan_wave, &b_tmp = slot ? ctx->cubtmp2 : ctx->cubtmp;
+         &b_wave = slot ? ctx->plan_wave2 : ctx->plan_wave,
+         &b_tmp = slot ? ctx->cubtmp2 : (st == ctx->stream3 && st != ctx->stream ? ctx->cubtmp3 : ctx->cubtmp);
   int sbase = (49152 + nb - 1) / nb;
   sbase = sbase < 8 ? 8 : (sbase > 64 ? 64 : sbase);
   if(sbase > ns)
@@ -630,6 +631,7 @@ static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int n
 static int run_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt, hipStream_t st)
 {
   int evi = (J.walk == GHIP_WALK_EWALD) ? 4 : 2;
+  ctx->plan_writer[J.walk == GHIP_WALK_EWALD ? 1 : 0] = st;
   HIPCHK(hipEventRecord(ctx->ev[evi], st));
   launch_walk_any(ctx, J.walk, ctx->gt, J.sg, J.nbuckets, nt, tgt, P<double>(ctx->sx),
                   P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
@@ -675,9 +677,16 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
     return GHIP_OK;
   const int *tgt = P<int>(ctx->tg_grav) + lo;
   WalkJob A, E;
-  GCHK(prepare_job(ctx, p, pair ? GHIP_WALK_NEWTON : walk, nt, 0, A));
+  // In a pair each walk's plan is built on the walk's own stream, next to the tail of the tree build
+  // on the main stream -- if that stream also ran the previous walk of the kind (whose per-bucket
+  // counts the plan reads); after a single walk on the main stream the plan stays there.
+  hipStream_t pn = (pair && ctx->plan_writer[0] == ctx->stream3) ? ctx->stream3 : nullptr;
+  hipStream_t pe = (pair && ctx->plan_writer[1] == ctx->stream2) ? ctx->stream2 : nullptr;
+  if(getenv("GHIP_PLAN_ON_MAIN"))
+    pn = nullptr;
+  GCHK(prepare_job(ctx, p, pair ? GHIP_WALK_NEWTON : walk, nt, 0, A, pn));
   if(pair)
-    GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E, ctx->stream2));
+    GCHK(prepare_job(ctx, p, GHIP_WALK_EWALD, nt, 1, E, pe));
 
   // OldAcc in tree order (forcetree.c:1850: aold = ErrTolForceAcc * P[target].OldAcc)
   // (multi-GPU: the tree's sources beyond the local particles are imported elements, never targets)

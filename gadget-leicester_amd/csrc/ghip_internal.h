@@ -256,6 +256,9 @@ struct ghip_ctx
   // visited per bucket in the previous call (double-buffered) and the scratch plan arrays
   DevBuf plan_steps[3][2], plan_nsub, plan_woff, plan_wave;
   int plan_nb[3] = {-1, -1, -1}, plan_ns[3] = {-1, -1, -1}, plan_cur[3] = {0, 0, 0};
+  hipStream_t plan_writer[3] = {nullptr, nullptr, nullptr};   // stream of the last walk of each kind: its
+                                                               // per-bucket counts feed the next plan
+  DevBuf cubtmp3;                                              // scan space of a plan built on stream3
 
   // ewald
   DevBuf ewtab;   // double[(EN+1)^3]: fcorrx scaled by 1/Box^2 (y, z by symmetry)
