@@ -611,8 +611,9 @@ struct WalkJob
 };
 
 // plan_on: the stream the wavefront plan and the counter resets are enqueued on (default: the main
-// stream).  The plan reads only what the previous walk of the same kind left behind, so in a pair
-// the Ewald walk's plan is built on the Ewald stream, next to the Newtonian one on the main stream.
+// stream).  The plan reads only what the previous walk of the same kind left behind, so in a sequence
+// of pairs each walk's plan is built on that walk's own stream (ghip_gravity_impl), off the main
+// stream's tree build.
 static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int nt, int slot,
                        WalkJob &J, hipStream_t plan_on = nullptr)
 {
