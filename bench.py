@@ -261,7 +261,14 @@ def main():
                 dom.migrate()
         force_step(gp)
         if not args.frozen:
-            fp.advance_timesteps(tl.kick_params())
+            # (everybody shares one bin in this workload: the host's timeline needs no recount)
+            fp.advance_timesteps(tl.kick_params(), counts=False)
+
+    # The host never waits for the device inside a step, except where the h iteration reads its
+    # unconverged count (underneath the gravity walks): drift and kick report errors at the next
+    # synchronisation, the tree build is enqueued without its node counts (include/ghip.h,
+    # ghip_set_async), statistics are kept per step on the device and read once after the run.
+    fp.set_async(True)
 
     # step 0 of a run (accel.c:61-68): Barnes-Hut pass to obtain OldAcc, then relative criterion;
     # advance_and_find_timesteps puts everybody into bin BIN
@@ -273,21 +280,17 @@ def main():
         step(gp_rel)
     sync()
 
-    phase_ms = {k: 0.0 for k in ("tree", "grav", "ewald", "dens", "hmax", "hydro")}
-    work = {k: 0 for k in ("grav_interactions", "ewald_interactions", "dens_neighbours",
-                           "hydro_pairs", "dens_iterations", "grav_wave_steps", "grav_targets")}
     migrated = 0
     dd_bytes = [0, 0, 0]
+    fp.run_begin(max(args.steps, 1))
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        fp.step_begin()
         step(gp_rel)
-        st = fp.stats()          # device-event times + interaction counters of this step
-        for k in phase_ms:
-            phase_ms[k] += st["ms_" + k]
-        for k in work:
-            work[k] += st[k]
+        fp.step_end()
         if dom is not None:
-            i = fp.dd_info()
+            i = fp.dd_info()     # host-side bookkeeping of the exchanges, no device access
             migrated += i["migrated_out"]
             dd_bytes[0] += i["bytes_migrate"]
             dd_bytes[1] += i["bytes_gravity"]
@@ -297,6 +300,13 @@ def main():
     if world > 1:
         elapsed = allreduce([elapsed], dist.ReduceOp.MAX)[0]
     K = max(args.steps, 1)
+    rs = fp.run_end()            # per-step device events and counters, summed over the run
+    st = fp.stats()
+    phase_ms = {k: rs["ms_" + k] for k in ("tree", "grav", "ewald", "dens", "hmax", "hydro")}
+    work = {k: rs[k] for k in ("grav_interactions", "ewald_interactions", "dens_neighbours",
+                               "hydro_pairs", "grav_wave_steps")}
+    work["dens_iterations"] = rs["dens_extra_iterations"]
+    work["grav_targets"] = st["grav_targets"]
     tot = [work["grav_interactions"], work["ewald_interactions"], work["dens_neighbours"],
            work["hydro_pairs"], fp.n]
     if world > 1:
@@ -308,7 +318,7 @@ def main():
 
     # the dominant kernel alone (outside the timed region): in the timed steps it shares the chip
     # with the Ewald walk and the SPH kernels, which stretches its own duration
-    iso_ms, iso_steps = None, None
+    iso_ms, iso_steps, iso_int = None, None, None
     if world == 1:
         iso, isteps = [], []
         for _ in range(3):
@@ -316,6 +326,7 @@ def main():
             s2 = fp.stats()
             iso.append(s2["ms_grav"])
             isteps.append(s2["grav_wave_steps"])
+            iso_int = s2["grav_interactions"]
         iso_ms, iso_steps = float(np.median(iso)), float(np.median(isteps))
 
     ms_per_step = 1e3 * elapsed / K
@@ -347,8 +358,17 @@ def main():
                 "n_gas": ngas_total,
                 "parallelism": parallelism,
             },
+            # how much of a step the host is responsible for: wall time per step minus the device's
+            # own span of a step (step-begin mark -> step-end mark on the device clock)
+            "host_gap_ms": ms_per_step - rs["ms_steps_device"] / max(rs["steps_timed"], 1),
+            "device_ms_per_step": rs["ms_steps_device"] / max(rs["steps_timed"], 1),
+            "device_idle_between_steps_ms": rs["ms_between_steps"] / max(rs["steps_timed"], 1),
+            "launches_per_step": rs["launches"] / K,
+            "blocking_syncs_per_step": rs["blocking_syncs"] / K,
+            # work-normalised throughput (the advancing state changes the work per step)
+            "interactions_per_s": (tot[0] + tot[1]) / elapsed,
             "roofline": walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world,
-                                      grav_int_all, n_total),
+                                      grav_int_all, n_total, iso_int),
             "phases_ms_rank0": {k: v / K for k, v in phase_ms.items()},
             "work_per_step_rank0": {"grav_interactions": work["grav_interactions"] / K,
                                     "ewald_interactions": work["ewald_interactions"] / K,
@@ -402,7 +422,8 @@ def main():
         dist.destroy_process_group()
 
 
-def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_int_all, n_total):
+def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_int_all, n_total,
+                  iso_int=None):
     """Dominant kernel: k_grav_walk<NEWTON>.  It is irregular fp64 pairwise work out of the caches
     (the walk records of c2 fit the L2 / Infinity Cache), so the bound that can actually bind is the
     fp64 VALU issue rate, not HBM:
@@ -458,6 +479,7 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
         "algorithmic_frac": (alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s > 0 else None,
         "hbm_frac": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if (traffic and kern_s > 0) else None,
         "interactions_per_particle": grav_int_all / K / n_total,
+        "ps_per_interaction": (1e12 * kern_s / grav_int) if grav_int else None,
         "lanes_interacting_per_visit": grav_int / (64.0 * wave_steps) if wave_steps else None,
         "note": "kernel_ms is the kernel's duration inside the timed steps, where it shares the chip "
                 "with the Ewald walk and the SPH kernels (DESIGN.md 4.3); *_alone: the same launch "
@@ -467,6 +489,8 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
     if iso_ms:
         s = 1e-3 * iso_ms
         r["kernel_ms_alone"] = iso_ms
+        r["ps_per_interaction_alone"] = (1e12 * s / iso_int) if iso_int else None
+        r["interactions_alone"] = iso_int
         r["frac_alone"] = issue_frac(iso_steps, s)
         r["algorithmic_frac_alone"] = alg_bytes / s / 1e9 / HBM_PEAK_GBS
         r["hbm_frac_alone"] = (traffic / s / 1e9 / HBM_PEAK_GBS) if traffic else None

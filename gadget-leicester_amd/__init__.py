@@ -57,8 +57,9 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if force or _newer(LIBGHIP, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lhipfft", "-ldl", "-o", LIBGHIP]
+    if force or _newer(LIBGHIP, objs + [os.path.join(CSRC, "ghip.map")]):
+        cmd = ([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs +
+               ["-Wl,--version-script=" + os.path.join(CSRC, "ghip.map"), "-lhipfft", "-ldl", "-o", LIBGHIP])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -145,6 +145,20 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class RunStats(C.Structure):
+    """ghip_run_stats: a run of steps without a host synchronisation per step"""
+    _fields_ = ([(k, C.c_longlong) for k in (
+        "steps", "steps_timed", "launches", "blocking_syncs", "grav_interactions",
+        "ewald_interactions", "dens_neighbours", "hydro_pairs", "grav_wave_steps",
+        "ewald_wave_steps", "dens_extra_iterations")] +
+        [(k, C.c_double) for k in (
+            "ms_tree", "ms_grav", "ms_ewald", "ms_dens", "ms_hmax", "ms_hydro", "ms_kick",
+            "ms_steps_device", "ms_between_steps", "ms_first_to_last")])
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class GhipError(RuntimeError):
     def __init__(self, code, msg):
         self.code = code
@@ -174,7 +188,9 @@ EXPORTS = [
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
     "ghip_dd_exchange_local", "ghip_dd_exchange_host", "ghip_dd_run", "ghip_dd_get_info",
     "ghip_sink_density", "ghip_sink_reset", "ghip_blackhole_evaluate", "ghip_blackhole_swallow",
-    "ghip_sink_get_marks", "ghip_sink_set_marks", "ghip_cooling_and_starformation"]
+    "ghip_sink_get_marks", "ghip_sink_set_marks", "ghip_cooling_and_starformation",
+    "ghip_set_async", "ghip_timebin_counts", "ghip_run_begin", "ghip_step_begin", "ghip_step_end",
+    "ghip_run_end"]
 
 
 def lib():
@@ -256,6 +272,12 @@ def lib():
         L.ghip_blackhole_evaluate.argtypes = [vp, C.POINTER(BhParams), C.c_int, vp, vp, vp, vp]
         L.ghip_blackhole_swallow.argtypes = [vp, C.POINTER(BhParams), C.c_int, vp, vp, vp, vp, vp,
                                              vp, vp, vp]
+        L.ghip_set_async.argtypes = [vp, C.c_int]
+        L.ghip_timebin_counts.argtypes = [vp, vp, vp]
+        L.ghip_run_begin.argtypes = [vp, C.c_int]
+        L.ghip_step_begin.argtypes = [vp]
+        L.ghip_step_end.argtypes = [vp]
+        L.ghip_run_end.argtypes = [vp, C.POINTER(RunStats)]
         L.ghip_sink_get_marks.argtypes = [vp, vp, vp]
         L.ghip_sink_set_marks.argtypes = [vp, vp, vp]
         L.ghip_cooling_and_starformation.argtypes = [vp, C.c_double, C.c_double, C.c_double,
@@ -424,12 +446,40 @@ class ForcePath:
             p.GravKickTable, p.HydroKickTable = [t.ctypes.data for t in self._pktabs]
         self._chk(self.L.ghip_pm_kick(self.h, C.byref(p)))
 
-    def advance_timesteps(self, params, kick_tables=None):
-        """ghip_advance_timesteps; returns (TimeBinCount[32], TimeBinCountSph[32]).  A timestep
-        failure raises GhipError with .endrun = the reference's endrun code."""
+    def set_async(self, on=True):
+        """ghip_set_async: drift / kick stop waiting for the device (errors surface at the next sync)"""
+        self._chk(self.L.ghip_set_async(self.h, int(bool(on))))
+
+    def run_begin(self, max_steps):
+        self._chk(self.L.ghip_run_begin(self.h, int(max_steps)))
+
+    def step_begin(self):
+        self._chk(self.L.ghip_step_begin(self.h))
+
+    def step_end(self):
+        self._chk(self.L.ghip_step_end(self.h))
+
+    def run_end(self):
+        s = RunStats()
+        self._chk(self.L.ghip_run_end(self.h, C.byref(s)))
+        return s.asdict()
+
+    def timebin_counts(self):
+        cnt = (C.c_longlong * 32)()
+        sph = (C.c_longlong * 32)()
+        self._chk(self.L.ghip_timebin_counts(self.h, cnt, sph))
+        return np.array(cnt[:], dtype=np.int64), np.array(sph[:], dtype=np.int64)
+
+    def advance_timesteps(self, params, kick_tables=None, counts=True):
+        """ghip_advance_timesteps; returns (TimeBinCount[32], TimeBinCountSph[32]) -- or None with
+        counts=False (no recount; under set_async the call then does not wait).  A timestep failure
+        raises GhipError with .endrun = the reference's endrun code."""
         if kick_tables is not None:
             self._ktabs = [np.ascontiguousarray(t, dtype=np.float64) for t in kick_tables]
             params.GravKickTable, params.HydroKickTable = [t.ctypes.data for t in self._ktabs]
+        if not counts:
+            self._chk(self.L.ghip_advance_timesteps(self.h, C.byref(params), None, None))
+            return None
         cnt = (C.c_longlong * 32)()
         sph = (C.c_longlong * 32)()
         rc = self.L.ghip_advance_timesteps(self.h, C.byref(params), cnt, sph)

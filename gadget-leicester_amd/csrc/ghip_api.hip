@@ -2,7 +2,52 @@
 // See include/ghip.h for what each entry point replaces in the reference.
 #include <cstdarg>
 
+#include <atomic>
+#include <dlfcn.h>
+
 #include "ghip_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// Launch counter.  Every `kernel<<<...>>>` of this library -- its own kernels and the rocPRIM /
+// hipCUB ones it calls -- ends in hipLaunchKernel.  The library carries a LOCAL definition of that
+// symbol (the export map keeps it out of the dynamic symbol table, so nobody else's calls are
+// touched) that counts and forwards to the runtime's.  bench.py reports launches per step from it.
+// ---------------------------------------------------------------------------------------------
+static std::atomic<long long> g_launches{0};
+typedef hipError_t (*launch_fn)(const void *, dim3, dim3, void **, size_t, hipStream_t);
+static launch_fn real_launch(void)
+{
+  static launch_fn fn = nullptr;
+  if(!fn)
+    {
+      void *p = dlvsym(RTLD_NEXT, "hipLaunchKernel", "hip_4.2");
+      if(!p)
+        p = dlsym(RTLD_NEXT, "hipLaunchKernel");
+      if(!p)
+        {
+          // the runtime this library is linked against, found through one of its other symbols
+          Dl_info info;
+          if(dladdr((void *) &hipMemsetAsync, &info) && info.dli_fname)
+            {
+              void *h = dlopen(info.dli_fname, RTLD_LAZY | RTLD_NOLOAD);
+              if(h)
+                p = dlsym(h, "hipLaunchKernel");
+            }
+        }
+      fn = (launch_fn) p;
+    }
+  return fn;
+}
+extern "C" hipError_t hipLaunchKernel(const void *function_address, dim3 numBlocks, dim3 dimBlocks,
+                                      void **args, size_t sharedMemBytes, hipStream_t stream)
+{
+  launch_fn fn = real_launch();
+  if(!fn)
+    return hipErrorNotInitialized;   // loud: every launch fails
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return fn(function_address, numBlocks, dimBlocks, args, sharedMemBytes, stream);
+}
+long long ghip_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -26,7 +71,13 @@ int ghip_ensure(ghip_ctx *ctx, DevBuf &b, size_t bytes)
   size_t want = bytes + bytes / 8 + 256;
   if(b.p)
     {
-      HIPCHK(hipStreamSynchronize(ctx->stream));
+      // (nothing may still be using the old block: the walks of a gravity pair run on streams of
+      // their own, and the host no longer waits for them at the end of every step)
+      HIPCHK(ghip_stream_sync(ctx, ctx->stream));
+      if(ctx->stream2)
+        HIPCHK(ghip_stream_sync(ctx, ctx->stream2));
+      if(ctx->stream3)
+        HIPCHK(ghip_stream_sync(ctx, ctx->stream3));
       HIPCHK(hipFree(b.p));
       b.p = nullptr;
       b.cap = 0;
@@ -53,6 +104,10 @@ int ghip_join_pair(ghip_ctx *ctx)
 
 int ghip_join(ghip_ctx *ctx)
 {
+  // (first: a tree built without waiting for its sizes is verified -- and, if it turned out bad,
+  // rebuilt with the gravity calls made since replayed -- before anything else relies on it)
+  if(ctx)
+    GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_join_pair(ctx));
   return ctx ? ghip_finish_gas_tree(ctx) : GHIP_OK;
 }
@@ -84,7 +139,7 @@ int ghip_check_device_errors(ghip_ctx *ctx)
     "a target had to open a pruned node of an imported (other shard's) tree: the locally "
     "essential tree was incomplete",
     "tree emission outside the element list or a malformed imported element",
-    "ghost import", "", "", "", ""};
+    "ghost import", "drift", "timestep", "", ""};
   for(int w = 0; w < GHIP_ERRW_COUNT; w++)
     {
       volatile int *e = ghip_errword(ctx, w);
@@ -92,6 +147,16 @@ int ghip_check_device_errors(ghip_ctx *ctx)
         {
           int v = *e;
           *e = 0;
+          // what an asynchronous ghip_drift / ghip_advance_timesteps would have returned itself
+          if(w == GHIP_ERRW_DRIFT)
+            return ghip_fail(ctx, GHIP_EINVAL, "ghip_drift: a particle is ahead of time1 (reference: "
+                             "endrun(12), predict.c:148)");
+          if(w == GHIP_ERRW_TIMESTEP)
+            {
+              ctx->timestep_endrun = v;
+              return ghip_fail(ctx, GHIP_ETIMESTEP, "ghip_advance_timesteps: the reference stops here with "
+                               "endrun(%d) (timestep.c:171/1082: 888, :1119: 818, :1233: 112313)", v);
+            }
           return ghip_fail(ctx, GHIP_EDEVICE, "device invariant %d broken (%d): %s", w, v, what[w]);
         }
     }
@@ -144,6 +209,13 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
         return GHIP_EHIP;
       }
   ctx->ev_ready = true;
+  ctx->evp = ctx->ev;
+  if(hipEventCreateWithFlags(&ctx->ev_sizes, hipEventDisableTiming) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_EHIP;
+    }
+  ctx->tree_async_ok = !(getenv("GHIP_TREE_SYNC") && atoi(getenv("GHIP_TREE_SYNC")) == 1);
   if(hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_least) != hipSuccess ||
      hipStreamCreateWithPriority(&ctx->stream3, hipStreamDefault, prio_least) != hipSuccess)
     {
@@ -179,6 +251,18 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
     }
   ctx->pinned_cap = 1024;
   memset(ctx->pinned, 0, 1024);
+  // the trees' sizes: on the device and mirrored in pinned memory ([128..] of the block above)
+  ctx->gt.hsz = reinterpret_cast<TreeSizes *>(reinterpret_cast<char *>(ctx->pinned) + 128);
+  ctx->st.hsz = ctx->gt.hsz + 1;
+  if(ghip_ensure(ctx, ctx->gt.dsz, sizeof(TreeSizes)) != GHIP_OK ||
+     ghip_ensure(ctx, ctx->st.dsz, sizeof(TreeSizes)) != GHIP_OK ||
+     hipMemset(ctx->gt.dsz.p, 0, sizeof(TreeSizes)) != hipSuccess ||
+     hipMemset(ctx->st.dsz.p, 0, sizeof(TreeSizes)) != hipSuccess ||
+     ghip_ensure(ctx, ctx->run_acc, 80 * 8) != GHIP_OK || hipMemset(ctx->run_acc.p, 0, 80 * 8) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_ENOMEM;
+    }
   // make every event "recorded" so that elapsed-time queries never fault
   for(int i = 0; i < 16; i++)
     (void) hipEventRecord(ctx->ev[i], ctx->stream);
@@ -190,7 +274,8 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
 static void free_tree(TreeDev &t)
 {
   DevBuf *bs[] = {&t.key, &t.skey, &t.idx, &t.perm, &t.iperm, &t.cpl, &t.cnt, &t.nb,
-                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2, &t.phkey, &t.phorder, &t.slvl};
+                  &t.xm,  &t.cl,   &t.lk,  &t.aux, &t.seg_start, &t.seg_nanc, &t.seg_anc, &t.mq, &t.mq2, &t.phkey, &t.phorder, &t.slvl,
+                  &t.father, &t.arrived, &t.dsz};
   for(DevBuf *b : bs)
     free_buf(*b);
 }
@@ -235,6 +320,11 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(ctx->ev_ready)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
+  if(ctx->ev_sizes)
+    (void) hipEventDestroy(ctx->ev_sizes);
+  for(hipEvent_t e : ctx->ev_ring)
+    (void) hipEventDestroy(e);
+  free_buf(ctx->run_acc);
   if(ctx->evx_ready)
     {
       for(int i = 0; i < 4; i++)
@@ -269,7 +359,7 @@ extern "C" int ghip_sync(ghip_ctx *ctx)
     GHIP_JOIN(ctx);
   if(!ctx)
     return GHIP_EINVAL;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   return ghip_check_device_errors(ctx);
 }
 
@@ -381,7 +471,7 @@ extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
         cnt, 3, P<double>(ctx->stage), P<double>(ctx->f[field]));
       HIPCHK(hipGetLastError());
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   if(field == GHIP_F_POS || field == GHIP_F_MASS || field == GHIP_F_TYPE)
     {
       ctx->gt.built = false;
@@ -412,7 +502,7 @@ extern "C" int ghip_get_field(ghip_ctx *ctx, int field, void *host)
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(host, ctx->stage.p, bytes, hipMemcpyDeviceToHost, st));
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return ghip_check_device_errors(ctx);
 }
 
@@ -569,7 +659,7 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
     return GHIP_OK;
   GCHK(upload_p_block(ctx, Pp, lay));
   GCHK(upload_s_block(ctx, Sp, lay));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   ctx->gt.built = false;
   ctx->st.built = false;
   ctx->gas_wait_upload = false;
@@ -592,7 +682,7 @@ extern "C" int ghip_upload_aos_particles(ghip_ctx *ctx, const void *Pp, const gh
   if(numpart == 0)
     return GHIP_OK;
   GCHK(upload_p_block(ctx, Pp, lay));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   ctx->gt.built = false;
   ctx->st.built = false;
   ctx->gas_wait_upload = ngas > 0;   // (whatever joins in between must leave the gas tree deferred)
@@ -606,7 +696,7 @@ extern "C" int ghip_upload_aos_gas(ghip_ctx *ctx, const void *Sp, const ghip_lay
   if(!ctx || !lay || (ctx->ngas > 0 && (!Sp || lay->s_stride <= 0)))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_upload_aos_gas: bad arguments");
   GCHK(upload_s_block(ctx, Sp, lay));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   ctx->gas_wait_upload = false;
   return GHIP_OK;
 }
@@ -671,7 +761,7 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
     HIPCHK(hipMemcpyAsync(Pp, ip, n * lay->p_stride, hipMemcpyDeviceToHost, st));
   if(touchS)
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return ghip_check_device_errors(ctx);
 }
 
@@ -728,7 +818,7 @@ extern "C" int ghip_download_aos_kick(ghip_ctx *ctx, void *Pp, void *Sp, const g
   HIPCHK(hipMemcpyAsync(Pp, ip, n * lay->p_stride, hipMemcpyDeviceToHost, st));
   if(ng > 0)
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return ghip_check_device_errors(ctx);
 }
 
@@ -761,7 +851,7 @@ extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
     {
       HIPCHK(hipMemcpyAsync(ctx->act_host_idx.p, idx, (size_t) nactive * 4, hipMemcpyHostToDevice,
                             ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(ghip_stream_sync(ctx, ctx->stream));
     }
   ctx->nactive = nactive;
   ctx->lists_dirty = true;
@@ -818,7 +908,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   if(!ctx || !out)
     return GHIP_EINVAL;
   GHIP_JOIN(ctx);
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   ghip_stats &S = ctx->stats;
   if(ctx->counters.p)
     {
@@ -833,7 +923,7 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
     }
   auto el = [&](int a, int b) {
     float ms = 0;
-    if(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess)
+    if(hipEventElapsedTime(&ms, ctx->evp[a], ctx->evp[b]) != hipSuccess)
       ms = 0;
     return ms;
   };
@@ -846,6 +936,139 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   S.ms_kick = el(12, 13);
   S.ms_pm = el(14, 15);
   *out = S;
+  return ghip_check_device_errors(ctx);
+}
+
+extern "C" int ghip_set_async(ghip_ctx *ctx, int on)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  if(!on && ctx->async)
+    {
+      // leaving asynchronous mode: whatever was deferred is reported now
+      HIPCHK(ghip_stream_sync(ctx, ctx->stream));
+      ctx->async = false;
+      return ghip_check_device_errors(ctx);
+    }
+  ctx->async = (on != 0);
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics of a run of steps without a host synchronisation per step
+// ---------------------------------------------------------------------------------------------
+#define RUN_EV (GHIP_NEV + 2)   // events per ring slot: the phase events + step begin / end marks
+
+// counters of the step's calls (each phase resets its own at its start) summed into the run's
+__global__ void k_run_accumulate(const unsigned long long *__restrict__ c, unsigned long long *__restrict__ acc)
+{
+  // (the walks add to acc[0], [1], [4], [5] themselves: interactions and element visits)
+  if(threadIdx.x == 0)
+    acc[2] += c[4];   // neighbours of the step's density passes
+  if(threadIdx.x == 1)
+    acc[3] += c[6];   // pairs of its hydro pass
+}
+
+extern "C" int ghip_run_begin(ghip_ctx *ctx, int max_steps)
+{
+  if(!ctx || max_steps < 1)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t want = (size_t) max_steps * RUN_EV;
+  while(ctx->ev_ring.size() < want)
+    {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      ctx->ev_ring.push_back(e);
+    }
+  ctx->ring_slots = max_steps;
+  ctx->ring_cur = -1;
+  ctx->run_steps = 0;
+  ctx->run_dens_iter = 0;
+  ctx->run_syncs0 = ctx->n_syncs;
+  ctx->run_launches0 = ghip_launch_count();
+  HIPCHK(hipMemsetAsync(ctx->run_acc.p, 0, 16 * 8, ctx->stream));
+  return GHIP_OK;
+}
+
+extern "C" int ghip_step_begin(ghip_ctx *ctx)
+{
+  if(!ctx || ctx->ring_slots <= 0)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_step_begin: call ghip_run_begin first");
+  ctx->ring_cur++;
+  ctx->evp = &ctx->ev_ring[(size_t) (ctx->ring_cur % ctx->ring_slots) * RUN_EV];
+  // (on the main stream, which is in order: after the previous step's end mark)
+  HIPCHK(hipEventRecord(ctx->evp[GHIP_NEV], ctx->stream));
+  return GHIP_OK;
+}
+
+extern "C" int ghip_step_end(ghip_ctx *ctx)
+{
+  if(!ctx || ctx->ring_slots <= 0 || ctx->ring_cur < 0)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_step_end: no step in progress");
+  GCHK(ghip_join_pair(ctx));   // (a gravity pair still in flight belongs to this step)
+  k_run_accumulate<<<1, 64, 0, ctx->stream>>>(P<unsigned long long>(ctx->counters),
+                                              P<unsigned long long>(ctx->run_acc));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->evp[GHIP_NEV + 1], ctx->stream));
+  ctx->run_steps++;
+  ctx->run_dens_iter += ctx->stats.dens_iterations;
+  return GHIP_OK;
+}
+
+extern "C" int ghip_run_end(ghip_ctx *ctx, ghip_run_stats *out)
+{
+  if(!ctx || !out || ctx->ring_slots <= 0)
+    return GHIP_EINVAL;
+  memset(out, 0, sizeof(*out));
+  out->launches = ghip_launch_count() - ctx->run_launches0;
+  out->blocking_syncs = ctx->n_syncs - ctx->run_syncs0;
+  GHIP_JOIN(ctx);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  unsigned long long acc[6];
+  HIPCHK(hipMemcpy(acc, ctx->run_acc.p, sizeof(acc), hipMemcpyDeviceToHost));
+  out->steps = ctx->run_steps;
+  out->grav_interactions = (long long) acc[0];
+  out->ewald_interactions = (long long) acc[1];
+  out->dens_neighbours = (long long) acc[2];
+  out->hydro_pairs = (long long) acc[3];
+  out->grav_wave_steps = (long long) acc[4];
+  out->ewald_wave_steps = (long long) acc[5];
+  out->dens_extra_iterations = ctx->run_dens_iter;
+  auto el = [](hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if(hipEventElapsedTime(&ms, a, b) != hipSuccess)
+      ms = 0;   // (a phase that did not run in that step)
+    return (double) ms;
+  };
+  const long long timed = ctx->run_steps < ctx->ring_slots ? ctx->run_steps : ctx->ring_slots;
+  out->steps_timed = timed;
+  const long long first = ctx->run_steps - timed;
+  hipEvent_t *prev = nullptr, *e0 = nullptr;
+  for(long long k = first; k < ctx->run_steps; k++)
+    {
+      hipEvent_t *e = &ctx->ev_ring[(size_t) (k % ctx->ring_slots) * RUN_EV];
+      out->ms_tree += el(e[0], e[1]);
+      out->ms_grav += el(e[2], e[3]);
+      out->ms_ewald += el(e[4], e[5]);
+      out->ms_dens += el(e[6], e[7]);
+      out->ms_hmax += el(e[8], e[9]);
+      out->ms_hydro += el(e[10], e[11]);
+      out->ms_kick += el(e[12], e[13]);
+      out->ms_steps_device += el(e[GHIP_NEV], e[GHIP_NEV + 1]);
+      if(prev)
+        out->ms_between_steps += el(prev[GHIP_NEV + 1], e[GHIP_NEV]);
+      else
+        e0 = e;
+      prev = e;
+    }
+  if(e0 && prev)
+    out->ms_first_to_last = el(e0[GHIP_NEV], prev[GHIP_NEV + 1]);
+  ctx->evp = ctx->ev;   // back to the fixed event set of ghip_get_stats
+  ctx->ring_slots = 0;
+  ctx->ring_cur = -1;
   return ghip_check_device_errors(ctx);
 }
 
@@ -874,6 +1097,6 @@ extern "C" int ghip_tree_dump(ghip_ctx *ctx, int which, int *nelem, double *xm4,
     HIPCHK(hipMemcpyAsync(aux, t.aux.p, ne * 8, hipMemcpyDeviceToHost, st));
   if(perm)
     HIPCHK(hipMemcpyAsync(perm, t.perm.p, (size_t) t.n * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }

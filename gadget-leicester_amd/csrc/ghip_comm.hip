@@ -203,7 +203,7 @@ extern "C" int ghip_dd_exchange(ghip_ctx *ctx)
   NCHK(g_rccl.AllGather(dmine, dall, (size_t) P_ * 4, ncclChar, comm, st));
   std::vector<int> cnt((size_t) P_ * P_);
   HIPCHK(hipMemcpyAsync(cnt.data(), dall, (size_t) P_ * P_ * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   recv_layout(x, me, P_, cnt.data());
   GCHK(ghip_ensure(ctx, *x.recv, (size_t) (x.rtotal > 0 ? x.rtotal : 1) * x.bytes));
   NCHK(g_rccl.GroupStart());
@@ -251,12 +251,12 @@ extern "C" int ghip_dd_exchange_host(ghip_ctx *ctx,
     {
       std::vector<char> hs(x.bytes), hr(x.bytes * P_);
       HIPCHK(hipMemcpyAsync(hs.data(), x.send, x.bytes, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       if(allgather(user, hs.data(), x.bytes, hr.data()) != 0)
         return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd_exchange_host: the caller's all-gather failed");
       GCHK(ghip_ensure(ctx, *x.recv, x.bytes * P_));
       HIPCHK(hipMemcpyAsync(x.recv->p, hr.data(), x.bytes * P_, hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       D.bytes_sent[D.op] += (long long) x.bytes * (P_ - 1);
       x.kind = 0;
       return GHIP_OK;
@@ -286,7 +286,7 @@ extern "C" int ghip_dd_exchange_host(ghip_ctx *ctx,
   std::vector<char> hs(blk), hr(blk * P_);
   if(mytotal > 0)
     HIPCHK(hipMemcpyAsync(hs.data(), x.send, (size_t) mytotal * x.bytes, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   if(allgather(user, hs.data(), blk, hr.data()) != 0)
     return ghip_fail(ctx, GHIP_ECOMM, "ghip_dd_exchange_host: the caller's all-gather failed");
   recv_layout(x, me, P_, cnt.data());
@@ -300,7 +300,7 @@ extern "C" int ghip_dd_exchange_host(ghip_ctx *ctx,
                             hr.data() + (size_t) src * blk + (size_t) o * x.bytes,
                             (size_t) x.rcount[src] * x.bytes, hipMemcpyHostToDevice, st));
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int dst = 0; dst < P_; dst++)
     if(dst != me)
       D.bytes_sent[D.op] += (long long) x.scount[dst] * (long long) x.bytes;
@@ -375,7 +375,7 @@ extern "C" int ghip_dd_exchange_local(ghip_ctx **ctxs, int n)
             if(dst != r)
               D.bytes_sent[D.op] += (long long) x.scount[dst] * (long long) x.bytes;
         }
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
     }
   for(int r = 0; r < n; r++)
     ctxs[r]->dd.x.kind = 0;

@@ -183,7 +183,7 @@ extern "C" int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host)
                                                       P<unsigned long long>(ctx->stage));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(keys_host, ctx->stage.p, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   return GHIP_OK;
 }
 
@@ -666,7 +666,7 @@ static int multi_select(ghip_ctx *ctx, int n, const unsigned long long *mask, De
   HIPCHK(hipGetLastError());
   int htot[GHIP_MAXRANKS];
   HIPCHK(hipMemcpyAsync(htot, tot, (size_t) P_ * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   SelOff S;
   int run = 0;
   for(int b = 0; b < GHIP_MAXRANKS; b++)
@@ -1089,7 +1089,7 @@ static int density_step(ghip_ctx *ctx)
           HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb, P<int>(ctx->tg_grav),
                                                P<int>(ctx->dflags), P<int>(D.gas_tgt), dnum, nt, st));
           HIPCHK(hipMemcpyAsync(&ngt, dnum, 4, hipMemcpyDeviceToHost, st));
-          HIPCHK(hipStreamSynchronize(st));
+          HIPCHK(ghip_stream_sync(ctx, st));
         }
       GCHK(build_groups(ctx, true, P<int>(D.gas_tgt), ngt));
       set_allgather(D, D.grp_own.p, (size_t) DD_TABLE * sizeof(DDGroup), &D.grp_all);
@@ -1158,7 +1158,7 @@ static int density_step(ghip_ctx *ctx)
             P<double>(ctx->dright), P<double>(D.h0), dr);
           double ratio = 0;
           HIPCHK(hipMemcpyAsync(&ratio, dr, 8, hipMemcpyDeviceToHost, st));
-          HIPCHK(hipStreamSynchronize(st));
+          HIPCHK(ghip_stream_sync(ctx, st));
           D.gh_growth = ratio;
           if(ratio > D.gh_margin)
             return ghip_fail(ctx, GHIP_EDEVICE,
@@ -1428,7 +1428,7 @@ static int migrate_step(ghip_ctx *ctx)
       unsigned long long tot[2];
       HIPCHK(hipMemcpyAsync(&tot[0], ro + n, 8, hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpyAsync(&tot[1], rn + nrecv, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       MigCounts C;
       C.kg = (int) (tot[0] & 0xffffffffULL);
       C.ko = (int) (tot[0] >> 32);
@@ -1452,7 +1452,7 @@ static int migrate_step(ghip_ctx *ctx)
       if(nrecv > 0)
         k_mig_move_new<<<cdiv(nrecv, 256), 256, 0, st>>>(nrecv, P<MigRec>(D.mig_recv), rn, C, Bn);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       for(int f = 0; f < GHIP_F_COUNT; f++)
         {
           DevBuf t = ctx->f[f];

@@ -20,7 +20,7 @@ __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
                         double *__restrict__ density, double *__restrict__ hsml,
                         const double *__restrict__ divvel, const double *__restrict__ entropy,
                         const double *__restrict__ dtentropy, double *__restrict__ pressure,
-                        int *__restrict__ err)
+                        int *__restrict__ err, int *errw)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
@@ -29,6 +29,8 @@ __global__ void k_drift(int n, int ngas, DriftK k, double *__restrict__ pos,
   if(k.time1 < time0)
     {
       atomicMax(err, 12);  // predict.c:148-152: endrun(12)
+      if(errw)             // asynchronous mode: the pinned word the next synchronising call checks
+        *(volatile int *) errw = 12;
       return;
     }
   if(k.time1 != time0)
@@ -132,13 +134,15 @@ extern "C" int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p)
     P<double>(ctx->f[GHIP_F_HYDROACCEL]), P<double>(ctx->f[GHIP_F_DENSITY]),
     P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_DIVVEL]),
     P<double>(ctx->f[GHIP_F_ENTROPY]), P<double>(ctx->f[GHIP_F_DTENTROPY]),
-    P<double>(ctx->f[GHIP_F_PRESSURE]), derr);
+    P<double>(ctx->f[GHIP_F_PRESSURE]), derr, ctx->async ? ghip_errword(ctx, GHIP_ERRW_DRIFT) : nullptr);
   HIPCHK(hipGetLastError());
-  int herr = 0;
-  HIPCHK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
   ctx->gt.built = false;  // positions moved: the trees are stale
   ctx->st.built = false;
+  if(ctx->async)
+    return GHIP_OK;   // (a particle ahead of time1 is reported by the next call that synchronises)
+  int herr = 0;
+  HIPCHK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   if(herr)
     return ghip_fail(ctx, GHIP_EINVAL,
                      "ghip_drift: a particle is ahead of time1 (reference: endrun(12), predict.c:148)");

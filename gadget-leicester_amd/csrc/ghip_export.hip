@@ -250,6 +250,6 @@ extern "C" int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int 
   HIPCHK(hipMemcpyAsync(Extnodes_base, dext, eb, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(Nextnode, dnn, (size_t) n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(Father, dfp, (size_t) n * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }

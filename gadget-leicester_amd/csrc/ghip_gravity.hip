@@ -222,7 +222,7 @@ extern "C" int ghip_ewald_get_table(ghip_ctx *ctx, double *host)
   std::vector<double> brick((size_t) GHIP_EW_DOUBLES);
   HIPCHK(hipMemcpyAsync(tmp.data(), ctx->ewtab.p, nt * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(brick.data(), ctx->ewbrick.p, brick.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   // the brick-tiled copy (and its overlap slots) must hold the same numbers
   for(int i = 0; i < E1; i++)
     for(int j = 0; j < E1; j++)
@@ -287,7 +287,7 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
           GCHK(ghip_ensure(ctx, ctx->srtab, sizeof(tab)));
           HIPCHK(hipMemcpyAsync(ctx->srtab.p, tab, sizeof(tab), hipMemcpyHostToDevice,
                                 ctx->stream));
-          HIPCHK(hipStreamSynchronize(ctx->stream));
+          HIPCHK(ghip_stream_sync(ctx, ctx->stream));
           ctx->srtab_ready = true;
         }
     }
@@ -310,6 +310,8 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   // >= 2048 elements per segment, at most 256 segments: the segment is the unit of work a
   // wavefront cannot split, and a bucket spends most of its steps in the one or two segments that
   // hold its own neighbourhood (measured at c2: 64 -> 256 segments: 12.2 -> 10.8 ms)
+  // (t.nelem: exact after a synchronous build, the last verified build's after an asynchronous one --
+  // any granularity is valid, the kernel cuts the list the device knows)
   int ns = t.nelem / 2048;
   if(ns < 1)
     ns = 1;
@@ -362,20 +364,21 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   GCHK(ghip_ensure(ctx, t.seg_start, (size_t) so * 4));
   GCHK(ghip_ensure(ctx, t.seg_nanc, (size_t) no * 4));
   GCHK(ghip_ensure(ctx, t.seg_anc, (size_t) no * GHIP_MAXANC * 4));
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
   k_build_segments<<<cdiv(total, 64), 64, 0, ctx->stream>>>(
-    t.nelem, P<int4>(t.lk), T, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
+    ts, P<int4>(t.lk), T, P<int>(t.seg_start), P<int>(t.seg_nanc), P<int>(t.seg_anc));
   HIPCHK(hipGetLastError());
   if(!walk_records)
     return GHIP_OK;
-  if((long long) t.nelem + 2 >= (1LL << 26))
+  const long long ce = (long long) t.n + t.cap_nodes;   // elements the buffers hold
+  if(ce + 2 >= (1LL << 26))
     return ghip_fail(ctx, GHIP_EINVAL, "the walk addresses its 64-byte element records by a 32-bit byte "
-                     "offset: %d elements are more than 2^26", t.nelem);
-  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(WalkHot)));
-  GCHK(ghip_ensure(ctx, t.mq2, (size_t) (t.nelem + 1) * sizeof(WalkCold)));
-  k_fill_elems<<<cdiv(t.nelem, 256), 256, 0, ctx->stream>>>(t.nelem, P<double4>(t.xm),
-                                                           P<double4>(t.cl), P<int4>(t.lk),
-                                                           P<double>(t.aux), P<WalkHot>(t.mq),
-                                                           P<WalkCold>(t.mq2));
+                     "offset: room for %lld elements is more than 2^26", ce);
+  GCHK(ghip_ensure(ctx, t.mq, (size_t) (ce + 1) * sizeof(WalkHot)));
+  GCHK(ghip_ensure(ctx, t.mq2, (size_t) (ce + 1) * sizeof(WalkCold)));
+  k_fill_elems<<<cdiv(ce, 256), 256, 0, ctx->stream>>>(ts, P<double4>(t.xm), P<double4>(t.cl),
+                                                      P<int4>(t.lk), P<double>(t.aux),
+                                                      P<WalkHot>(t.mq), P<WalkCold>(t.mq2));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
@@ -552,7 +555,9 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
     P<float>(ctx->srtab), P<double>((UNEQ) && MODE == GHIP_WALK_EWALD ? ctx->ewbrick : ctx->ewtab),  \
-    pb.ax, pb.ay, pb.az, pb.cost, counter, pl)
+    pb.ax, pb.ay, pb.az, pb.cost, counter,                                                         \
+    P<unsigned long long>(ctx->run_acc) + (counter - P<unsigned long long>(ctx->counters) < 2       \
+                                             ? counter - P<unsigned long long>(ctx->counters) : 8), pl)
   // The Ewald walk has no softening rule; its UNEQUAL instantiation is the variant that reads the
   // brick-tiled table (the default; GHIP_EW_BRICK=0 selects the plain rows).  Alone the walk is bound
   // by the L2 requests of its gathers and the bricks cut them (6.3 -> 4.5 ms at c2); inside a pair
@@ -633,12 +638,12 @@ static int run_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt, hip
 {
   int evi = (J.walk == GHIP_WALK_EWALD) ? 4 : 2;
   ctx->plan_writer[J.walk == GHIP_WALK_EWALD ? 1 : 0] = st;
-  HIPCHK(hipEventRecord(ctx->ev[evi], st));
+  HIPCHK(hipEventRecord(ctx->evp[evi], st));
   launch_walk_any(ctx, J.walk, ctx->gt, J.sg, J.nbuckets, nt, tgt, P<double>(ctx->sx),
                   P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
                   P<double>(ctx->soldacc), J.k, J.counter, J.plan, J.pb, st);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[evi + 1], st));
+  HIPCHK(hipEventRecord(ctx->evp[evi + 1], st));
   return GHIP_OK;
 }
 
@@ -661,6 +666,15 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   const bool pair = (walk == GHIP_WALK_NEWTON_EWALD);
   if(pair && !p->periodic)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity: the Newton+Ewald pair needs periodic = 1");
+  // (an asynchronously built tree stays unverified here: the walks read its sizes on the device.  The
+  // call is logged so that it can be replayed should the verification reject the tree.)
+  if(ctx->tree_unverified)
+    {
+      ghip_ctx::GravCall c;
+      c.p = *p;
+      c.walk = walk;
+      ctx->grav_log.push_back(c);
+    }
   GCHK(ghip_build_target_lists(ctx));
   hipStream_t st = ctx->stream;
   int n = ctx->n;
@@ -790,7 +804,7 @@ extern "C" int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, i
   std::vector<double> r((size_t) nt * 3);
   HIPCHK(hipMemcpyAsync(r.data(), dacc, (size_t) nt * 24, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(ninteractions, dcost, (size_t) nt * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int a = 0; a < nt; a++)
     {
       acc[3 * (size_t) a] = r[a];

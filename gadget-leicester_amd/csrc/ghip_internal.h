@@ -40,10 +40,27 @@ struct DevBuf
   size_t cap = 0;  // bytes
 };
 
+// Sizes of a tree as the DEVICE knows them: written by k_tree_info at the end of the counting stage
+// of a build, into device memory (the build's later kernels and every hot-path consumer read them
+// there) and into a pinned host mirror (the host learns them without a copy at its next
+// verification point, ghip_tree_verify).  The host therefore enqueues a whole build, and the walks
+// behind it, without waiting for the node count.
+struct TreeSizes
+{
+  int nelem;      // n + nnodes; 0 while the tree is unusable (bad != 0): every consumer then does nothing
+  int nnodes;
+  int maxlevel;
+  int bad;        // 1: more nodes than the element buffers hold; 2: key runs too long for the 32-bit sort
+  int n;          // sources
+  int gen;        // build generation (host counter): tells a fresh mirror from a stale one
+  int longrun;
+  int pad;
+};
+
 struct TreeDev
 {
   int n = 0;        // particles in this tree
-  int nnodes = 0;
+  int nnodes = 0;   // (host copies: exact after a synchronous build or after ghip_tree_verify)
   int nelem = 0;    // n + nnodes
   int maxlevel = GHIP_BITS;  // deepest node level
   // sort
@@ -58,6 +75,11 @@ struct TreeDev
   int seg_ns[3] = {1, 1, 1}, seg_soff[3] = {0, 0, 0}, seg_noff[3] = {0, 0, 0};   // fine / mid / coarse
   DevBuf mq, mq2;                      // WalkHot[nelem], WalkCold[nelem]: walk records (gravity tree)
   DevBuf slvl;                         // i32[n]: level of an imported pruned node in sorted order, 0: particle
+  DevBuf father, arrived;              // moment pass: per-level lists of the chunk-crossing nodes, their counts
+  DevBuf dsz;                          // TreeSizes on the device
+  TreeSizes *hsz = nullptr;            // its pinned host mirror
+  int cap_nodes = 0;                   // nodes the element buffers are sized for
+  int last_n = -1, last_nnodes = 0;    // the last verified build: sources, nodes
   bool built = false;
 };
 
@@ -246,7 +268,6 @@ struct ghip_ctx
   bool gas_pending = false;
   bool gas_wait_upload = false;   // ghip_upload_aos_particles done, ghip_upload_aos_gas not yet: the
                                    // deferred gas-tree work must not run on stale SphP fields
-  int gas_hinfo[3] = {0, 0, 0};
   hipEvent_t evx[4];               // pair ordering: inputs ready / Newton combined / Ewald combined /
                                    // Ewald walk kernel done (ghip_hydro waits for it)
   bool evx_ready = false;
@@ -282,7 +303,54 @@ struct ghip_ctx
                                     // SphP[].i.Injected_BH_Energy f64[ngas]
   int timestep_endrun = 0;   // endrun code of the last ghip_advance_timesteps failure
   bool ev_ready = false;
+
+  // ---- asynchronous tree build (ghip_tree.hip) ----
+  // A build whose particle number equals the previous build's is enqueued without the host waiting
+  // for the node counts: buffers are sized by capacity, every kernel reads the sizes on the device
+  // (TreeSizes).  The counts are VERIFIED -- the host waits for ev_sizes only, recorded right after the
+  // counting stage, not for the walks -- before anything persistent is modified on their basis
+  // (ghip_tree_verify: entry of ghip_density and of everything that joins).  A build that turns out
+  // bad (more nodes than the buffers hold, key runs too long for the 32-bit sort) left nelem = 0 on
+  // the device, so whatever ran on it did nothing; it is then repeated synchronously and the gravity
+  // calls made since are replayed from grav_log.
+  bool async = false;              // ghip_set_async: drift / kick report their errors at the next sync
+  bool tree_unverified = false;
+  bool tree_async_ok = true;       // GHIP_TREE_SYNC=1 switches the asynchronous build off
+  hipEvent_t ev_sizes = nullptr;
+  int build_gen = 0;
+  bool sort_wide = false;          // sticky: a build met key runs too long for the 32-bit sort
+  bool in_recover = false;
+  struct GravCall
+  {
+    ghip_grav_params p;
+    int walk;
+  };
+  std::vector<GravCall> grav_log;  // gravity calls since the last tree build
+
+  // ---- run statistics without a host synchronisation per step (ghip_run_begin / ghip_step_begin /
+  // ghip_step_end / ghip_get_run_stats): a ring of event sets, device-side accumulated counters ----
+  std::vector<hipEvent_t> ev_ring;     // [slots][GHIP_NEV + 2]: phase events + step begin / end marks
+  int ring_slots = 0, ring_cur = -1;   // ring_cur < 0: the fixed set ev[] is in use
+  hipEvent_t *evp = nullptr;           // the event set in use (ev[] or a ring slot)
+  long long run_steps = 0, run_syncs0 = 0, run_launches0 = 0, run_dens_iter = 0;
+  long long n_syncs = 0;               // blocking host waits inside the library since creation
+  DevBuf run_acc;                      // u64[16]: counters summed over the steps of a run
 };
+#define GHIP_NEV 16
+
+// every blocking wait of the host goes through these two (they are counted: ghip_run_stats)
+static inline hipError_t ghip_stream_sync(ghip_ctx *ctx, hipStream_t st)
+{
+  ctx->n_syncs++;
+  return hipStreamSynchronize(st);
+}
+static inline hipError_t ghip_event_sync(ghip_ctx *ctx, hipEvent_t e)
+{
+  ctx->n_syncs++;
+  return hipEventSynchronize(e);
+}
+long long ghip_launch_count(void);   // kernel launches issued through this library so far (ghip_api.hip)
+int ghip_tree_verify(ghip_ctx *ctx);  // tree.hip
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 // Device error words: ints in pinned, device-visible host memory that kernels set when an internal
@@ -292,6 +360,8 @@ int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 #define GHIP_ERRW_LET 1      // a target wanted to open a pruned node of another shard's tree
 #define GHIP_ERRW_TREE 2     // tree emission wrote outside the element list / malformed import
 #define GHIP_ERRW_GHOST 3    // spare
+#define GHIP_ERRW_DRIFT 4    // a particle was ahead of the drift target (reference: endrun(12), predict.c:148)
+#define GHIP_ERRW_TIMESTEP 5 // the endrun code of a failed timestep criterion (888, 818, 112313)
 #define GHIP_ERRW_COUNT 8
 // (one block per process, shared by its contexts: an error raised by a kernel of one logical shard
 // is seen by whichever context synchronises next)

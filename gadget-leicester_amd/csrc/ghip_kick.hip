@@ -52,8 +52,17 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
                                     const double *__restrict__ hsml,
                                     const double *__restrict__ maxsignalvel,
                                     int *__restrict__ timebin, int *__restrict__ ti_begstep,
-                                    int *__restrict__ err)
+                                    int *__restrict__ err, int *errw)
 {
+// (errw: asynchronous mode, the pinned word the next synchronising call checks)
+#define D_RAISE(code)                   \
+  do                                    \
+    {                                   \
+      atomicMax(err, (code));           \
+      if(errw)                          \
+        *(volatile int *) errw = (code); \
+    }                                   \
+  while(0)
   int a = blockIdx.x * blockDim.x + threadIdx.x;
   if(a >= nact)
     return;
@@ -107,13 +116,13 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
     dt = k.dtdisp;
   if(dt < k.mindt)
     {
-      atomicMax(err, 888);   // timestep.c:1082
+      D_RAISE(888);   // timestep.c:1082
       return;
     }
   int ti_step = (int) (dt / k.timebase);
   if(!(ti_step > 0 && ti_step < GHIP_TIMEBASE))
     {
-      atomicMax(err, 818);   // timestep.c:1119
+      D_RAISE(818);   // timestep.c:1119
       return;
     }
   // ---- advance_and_find_timesteps, timestep.c:146-175: power-of-two step, bin, synchronisation
@@ -123,7 +132,7 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
   ti_step = ti_min;
   if(ti_step == 1)
     {
-      atomicMax(err, 112313);   // get_timestep_bin, timestep.c:1233
+      D_RAISE(112313);   // get_timestep_bin, timestep.c:1233
       return;
     }
   int bin = ti_step ? 31 - __clz(ti_step) : 0;
@@ -140,7 +149,7 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
     }
   if((GHIP_TIMEBASE - k.ti_current) < ti_step)
     {
-      atomicMax(err, 888);   // timestep.c:171
+      D_RAISE(888);   // timestep.c:171
       return;
     }
   timebin[i] = bin;
@@ -203,6 +212,8 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
     vel[(size_t) j * n + i] = v[j];
 }
 
+#undef D_RAISE
+
 // TimeBinCount[] / TimeBinCountSph[] (allvars.h:337-338) recounted over all particles
 __global__ void k_timebin_histogram(int n, const int *__restrict__ type,
                                     const int *__restrict__ timebin,
@@ -223,6 +234,38 @@ __global__ void k_timebin_histogram(int n, const int *__restrict__ type,
   __syncthreads();
   if(threadIdx.x < 64 && h[threadIdx.x])
     atomicAdd(out + threadIdx.x, (unsigned long long) h[threadIdx.x]);
+}
+
+extern "C" int ghip_timebin_counts(ghip_ctx *ctx, long long *TimeBinCount, long long *TimeBinCountSph)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  if(TimeBinCount)
+    memset(TimeBinCount, 0, 32 * sizeof(long long));
+  if(TimeBinCountSph)
+    memset(TimeBinCountSph, 0, 32 * sizeof(long long));
+  const int n = ctx->n;
+  if(n == 0)
+    return GHIP_OK;
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
+  // (its own 64 words behind the run's accumulated counters)
+  unsigned long long *dhist = P<unsigned long long>(ctx->run_acc) + 16;
+  HIPCHK(hipMemsetAsync(dhist, 0, 64 * 8, st));
+  k_timebin_histogram<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]),
+                                                    P<int>(ctx->f[GHIP_F_TIMEBIN]), dhist);
+  HIPCHK(hipGetLastError());
+  unsigned long long hist[64];
+  HIPCHK(hipMemcpyAsync(hist, dhist, 64 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ghip_stream_sync(ctx, st));
+  for(int b = 0; b < 32; b++)
+    {
+      if(TimeBinCount)
+        TimeBinCount[b] = (long long) hist[b];
+      if(TimeBinCountSph)
+        TimeBinCountSph[b] = (long long) hist[32 + b];
+    }
+  return ghip_check_device_errors(ctx);
 }
 
 extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
@@ -283,7 +326,6 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   HIPCHK(hipMemsetAsync(derr, 0, 4, st));
   GCHK(ghip_ensure(ctx, ctx->stage, (2 * DRIFT_TABLE_LENGTH + 64) * 8));
   double *d = P<double>(ctx->stage);
-  unsigned long long *dhist = reinterpret_cast<unsigned long long *>(d + 2 * DRIFT_TABLE_LENGTH);
   if(k.comoving)
     {
       HIPCHK(hipMemcpyAsync(d, p->GravKickTable, DRIFT_TABLE_LENGTH * 8, hipMemcpyHostToDevice, st));
@@ -294,7 +336,7 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
     }
   const int nact = ctx->nactive < 0 ? n : ctx->nactive;
   const int *act = ctx->nactive < 0 ? nullptr : P<int>(ctx->act_host_idx);
-  HIPCHK(hipEventRecord(ctx->ev[12], st));
+  HIPCHK(hipEventRecord(ctx->evp[12], st));
   if(nact > 0)
     k_advance_timesteps<<<cdiv(nact, 256), 256, 0, st>>>(
       nact, act, n, ng, k, P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->f[GHIP_F_VEL]),
@@ -303,24 +345,23 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
       P<double>(ctx->f[GHIP_F_VELPRED]), P<double>(ctx->f[GHIP_F_ENTROPY]),
       P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_DENSITY]),
       P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]),
-      P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TI_BEGSTEP]), derr);
-  HIPCHK(hipEventRecord(ctx->ev[13], st));
-  HIPCHK(hipMemsetAsync(dhist, 0, 64 * 8, st));
-  k_timebin_histogram<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]),
-                                                    P<int>(ctx->f[GHIP_F_TIMEBIN]), dhist);
+      P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TI_BEGSTEP]), derr,
+      ctx->async ? ghip_errword(ctx, GHIP_ERRW_TIMESTEP) : nullptr);
+  HIPCHK(hipEventRecord(ctx->evp[13], st));
   HIPCHK(hipGetLastError());
+  const bool want_counts = TimeBinCount || TimeBinCountSph;
+  if(ctx->async && !want_counts)
+    return GHIP_OK;   // (a failed criterion is reported by the next call that synchronises)
   int herr = 0;
-  unsigned long long hist[64];
   HIPCHK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(hist, dhist, 64 * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  for(int b = 0; b < 32; b++)
+  if(want_counts)
     {
-      if(TimeBinCount)
-        TimeBinCount[b] = (long long) hist[b];
-      if(TimeBinCountSph)
-        TimeBinCountSph[b] = (long long) hist[32 + b];
+      int rc = ghip_timebin_counts(ctx, TimeBinCount, TimeBinCountSph);   // (synchronises)
+      if(rc != GHIP_OK && rc != GHIP_ETIMESTEP)
+        return rc;
     }
+  else
+    HIPCHK(ghip_stream_sync(ctx, st));
   if(herr)
     {
       ghip_fail(ctx, GHIP_ETIMESTEP,
@@ -328,6 +369,7 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
                 "(timestep.c:171/1082: 888, :1119: 818, :1233: 112313)",
                 herr);
       ctx->timestep_endrun = herr;
+      *ghip_errword(ctx, GHIP_ERRW_TIMESTEP) = 0;
       return GHIP_ETIMESTEP;
     }
   ctx->timestep_endrun = 0;
@@ -433,7 +475,7 @@ extern "C" int ghip_velocity_moments(ghip_ctx *ctx, double v2sum[6], double min_
   HIPCHK(hipGetLastError());
   double h[18];
   HIPCHK(hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int t = 0; t < 6; t++)
     {
       v2sum[t] = h[t];

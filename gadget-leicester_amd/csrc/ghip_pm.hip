@@ -263,10 +263,10 @@ extern "C" int ghip_pm_periodic(ghip_ctx *ctx, const ghip_pm_params *p)
     return GHIP_OK;
   hipStream_t st = ctx->stream;
   GCHK(pm_prepare(ctx, p->pmgrid));
-  HIPCHK(hipEventRecord(ctx->ev[14], st));
+  HIPCHK(hipEventRecord(ctx->evp[14], st));
   GCHK(pm_deposit(ctx, p));
   GCHK(pm_solve_and_interpolate(ctx, p));
-  HIPCHK(hipEventRecord(ctx->ev[15], st));
+  HIPCHK(hipEventRecord(ctx->evp[15], st));
   return GHIP_OK;
 }
 
@@ -300,7 +300,7 @@ int ghip_dd_pm_step(ghip_ctx *ctx)
   if(D.phase == 0)
     {
       GCHK(pm_prepare(ctx, p->pmgrid));
-      HIPCHK(hipEventRecord(ctx->ev[14], st));
+      HIPCHK(hipEventRecord(ctx->evp[14], st));
       GCHK(pm_deposit(ctx, p));
       ghip_dd_set_allgather(D, ctx->pm_rho.p, n3 * sizeof(double), &D.pm_all);
       D.phase = 1;
@@ -312,7 +312,7 @@ int ghip_dd_pm_step(ghip_ctx *ctx)
                                                                  P<double>(ctx->pm_rho));
       HIPCHK(hipGetLastError());
       GCHK(pm_solve_and_interpolate(ctx, p));
-      HIPCHK(hipEventRecord(ctx->ev[15], st));
+      HIPCHK(hipEventRecord(ctx->evp[15], st));
       D.op = 0;
       return 0;
     }

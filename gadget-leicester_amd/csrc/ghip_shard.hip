@@ -173,7 +173,7 @@ extern "C" int ghip_shard_pack(ghip_ctx *ctx, int group, void *dev_buf)
     group, cnt, per, tgt, P<int>(t.perm), ctx->n, ctx->ngas, f[0], f[1], f[2], f[3], f[4], f[5],
     f[6], P<int>(ctx->f[GHIP_F_GRAVCOST]), (double *) dev_buf);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's collective runs on its own stream
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));  // the caller's collective runs on its own stream
   return GHIP_OK;
 }
 
@@ -226,6 +226,6 @@ extern "C" int ghip_shard_unpack(ghip_ctx *ctx, int group, const void *dev_buf_a
     P<int>(t.perm), ctx->n, ctx->ngas, (const double *) dev_buf_all, f[0], f[1], f[2], f[3], f[4],
     f[5], f[6], P<int>(ctx->f[GHIP_F_GRAVCOST]), P<double>(ctx->gp), P<double>(ctx->gq));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   return GHIP_OK;
 }

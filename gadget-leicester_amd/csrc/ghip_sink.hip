@@ -215,7 +215,7 @@ static int gather_sinks(ghip_ctx *ctx, int nsink, const int *idx, const unsigned
       S[a].index = i;
       S[a].pad = 0;
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int a = 0; a < nsink; a++)
     S[a].timebin = tb[a];
   return GHIP_OK;
@@ -355,7 +355,7 @@ extern "C" int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, doubl
     {
       GCHK(sink_density_pass(ctx, p, nsink, drecs, dh, dslot, dout, I, ncur, 0));
       HIPCHK(hipMemcpyAsync(hout.data(), dout, (size_t) nsink * 48, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       ncur = sink_iterate(p, ngb_factor, nsink, hout.data(), ncur, I);
       if(ncur > 0)
         {
@@ -377,7 +377,7 @@ extern "C" int ghip_sink_density(ghip_ctx *ctx, const ghip_dens_params *p, doubl
       HIPCHK(hipMemcpyAsync(P<double>(ctx->f[GHIP_F_HSML]) + sink_idx[a], &I.h[a], 8,
                             hipMemcpyHostToDevice, st));
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   if(iterations)
     *iterations = iter;
   return GHIP_OK;
@@ -678,7 +678,7 @@ extern "C" int ghip_blackhole_evaluate(ghip_ctx *ctx, const ghip_bh_params *p, i
                                       bh_kparams(p), P<unsigned int>(ctx->bh_swallow),
                                       P<double>(ctx->bh_injected));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 
@@ -725,7 +725,7 @@ extern "C" int ghip_blackhole_swallow(ghip_ctx *ctx, const ghip_bh_params *p, in
   HIPCHK(hipMemcpyAsync(out.data(), dout, (size_t) 9 * nsink * 8, hipMemcpyDeviceToHost, st));
   for(int a = 0; a < nsink; a++)
     HIPCHK(hipMemcpyAsync(&vict[a], dvict + sink_idx[a], 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int a = 0; a < nsink; a++)
     {
       acc_mass[a] = out[a];
@@ -756,7 +756,7 @@ extern "C" int ghip_sink_get_marks(ghip_ctx *ctx, unsigned int *swallow_id, doub
   if(injected_energy && ctx->ngas > 0)
     HIPCHK(hipMemcpyAsync(injected_energy, ctx->bh_injected.p, (size_t) ctx->ngas * 8,
                           hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 
@@ -773,7 +773,7 @@ extern "C" int ghip_sink_set_marks(ghip_ctx *ctx, const unsigned int *swallow_id
   if(injected_energy && ctx->ngas > 0)
     HIPCHK(hipMemcpyAsync(ctx->bh_injected.p, injected_energy, (size_t) ctx->ngas * 8,
                           hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 
@@ -856,7 +856,7 @@ extern "C" int ghip_cooling_and_starformation(ghip_ctx *ctx, double Timebase_int
   HIPCHK(hipGetLastError());
   if(flag_sink_host)
     HIPCHK(hipMemcpyAsync(flag_sink_host, ctx->dflags.p, (size_t) ng * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 
@@ -923,7 +923,7 @@ static int dd_sink_sum_parts(ghip_ctx *ctx, int k, std::vector<double> &parts, s
   parts.resize(per * D.nranks);
   sums.assign(per, 0.0);
   HIPCHK(hipMemcpyAsync(parts.data(), D.sk_parts.p, per * D.nranks * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   for(int r = 0; r < D.nranks; r++)
     for(size_t q = 0; q < per; q++)
       sums[q] += parts[(size_t) r * per + q];
@@ -949,7 +949,7 @@ int ghip_dd_sink_step(ghip_ctx *ctx)
       GCHK(ghip_ensure(ctx, D.sk_send, (size_t) (nloc > 0 ? nloc : 1) * sizeof(SinkRec)));
       if(nloc > 0)
         HIPCHK(hipMemcpyAsync(D.sk_send.p, S.data(), (size_t) nloc * sizeof(SinkRec), hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));   // S goes out of scope
+      HIPCHK(ghip_stream_sync(ctx, st));   // S goes out of scope
       int scount[GHIP_MAXRANKS], soff[GHIP_MAXRANKS];
       for(int r = 0; r < D.nranks; r++)
         {
@@ -978,7 +978,7 @@ int ghip_dd_sink_step(ghip_ctx *ctx)
         {
           std::vector<SinkRec> all(ns);
           HIPCHK(hipMemcpyAsync(all.data(), D.sk_all.p, (size_t) ns * sizeof(SinkRec), hipMemcpyDeviceToHost, st));
-          HIPCHK(hipStreamSynchronize(st));
+          HIPCHK(ghip_stream_sync(ctx, st));
           sink_iter_init(D.sk_it, ns);
           for(int a = 0; a < ns; a++)
             D.sk_it.h[a] = all[a].h;
@@ -999,7 +999,7 @@ int ghip_dd_sink_step(ghip_ctx *ctx)
                                            P<double>(ctx->f[GHIP_F_DENSITY]), bh_kparams(A.bh),
                                            P<unsigned int>(ctx->bh_swallow), P<double>(ctx->bh_injected));
           HIPCHK(hipGetLastError());
-          HIPCHK(hipStreamSynchronize(st));
+          HIPCHK(ghip_stream_sync(ctx, st));
           D.op = 0;
           return 0;
         }
@@ -1056,7 +1056,7 @@ int ghip_dd_sink_step(ghip_ctx *ctx)
           HIPCHK(hipMemcpyAsync(P<double>(ctx->f[GHIP_F_HSML]) + A.sink_idx[a], &I.h[g], 8,
                                 hipMemcpyHostToDevice, st));
         }
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       D.op = 0;
       return 0;
     }
@@ -1070,7 +1070,7 @@ int ghip_dd_sink_step(ghip_ctx *ctx)
       std::vector<int> vict(nloc > 0 ? nloc : 1);
       for(int a = 0; a < nloc; a++)
         HIPCHK(hipMemcpyAsync(&vict[a], dvict + A.sink_idx[a], 4, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
       for(int a = 0; a < nloc; a++)
         {
           const int g = D.sk_off + a;

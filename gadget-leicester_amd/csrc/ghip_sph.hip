@@ -274,7 +274,7 @@ __device__ __forceinline__ double d_slot_max(double v)
 // added in fixed order at the end.
 template <int TG>
 __global__ void __launch_bounds__(64)
-k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp, int nt,
+k_density(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, const double *__restrict__ gp, int nt,
           int nsub, const int *__restrict__ tgt, const double *__restrict__ hcur, BoxK b,
           double *__restrict__ prho, double *__restrict__ pnum, double *__restrict__ pdh,
           double *__restrict__ pdiv, double *__restrict__ prot,
@@ -307,6 +307,7 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
   DensAcc A = {0, 0, 0, 0, 0, 0, 0, 0};
   const BucketBox BB = d_bucket_box(valid, px, py, pz, h, b);
 
+  const int nelem = __builtin_amdgcn_readfirstlane(ts->nelem);   // the gas tree's elements, as the device counted them
   int e = 0;
   while(e < nelem)
     {
@@ -383,12 +384,12 @@ k_density(int nelem, const SphNode *__restrict__ nodes, const double *__restrict
 }
 
 // SphNode records from the gas tree's arrays; k_sph_nodes_hmax refreshes only hmax
-__global__ void k_fill_sph_nodes(int nelem, const double4 *__restrict__ cl,
+__global__ void k_fill_sph_nodes(const TreeSizes *__restrict__ ts, const double4 *__restrict__ cl,
                                  const int4 *__restrict__ lk, const double *__restrict__ aux,
                                  SphNode *__restrict__ out)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
+  if(e >= ts->nelem)
     return;
   double4 c = cl[e];
   int4 k = lk[e];
@@ -406,11 +407,11 @@ __global__ void k_fill_sph_nodes(int nelem, const double4 *__restrict__ cl,
   out[e] = r;
 }
 
-__global__ void k_sph_nodes_hmax(int nelem, const double *__restrict__ aux,
+__global__ void k_sph_nodes_hmax(const TreeSizes *__restrict__ ts, const double *__restrict__ aux,
                                  SphNode *__restrict__ nodes)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e < nelem)
+  if(e < ts->nelem)
     nodes[e].hmax = aux[e];
 }
 
@@ -419,13 +420,15 @@ int ghip_sph_fill_nodes(ghip_ctx *ctx, bool hmax_only)
   TreeDev &t = ctx->st;
   if(t.n == 0)
     return GHIP_OK;
-  GCHK(ghip_ensure(ctx, t.mq, (size_t) (t.nelem + 1) * sizeof(SphNode)));
+  const int ce = t.n + t.cap_nodes;   // elements the buffers hold; the kernels read the count on the device
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
+  GCHK(ghip_ensure(ctx, t.mq, (size_t) (ce + 1) * sizeof(SphNode)));
   if(hmax_only)
-    k_sph_nodes_hmax<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(t.nelem, P<double>(t.aux),
-                                                                  P<SphNode>(t.mq));
+    k_sph_nodes_hmax<<<cdiv(ce, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(ts, P<double>(t.aux),
+                                                                             P<SphNode>(t.mq));
   else
-    k_fill_sph_nodes<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(
-      t.nelem, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<SphNode>(t.mq));
+    k_fill_sph_nodes<<<cdiv(ce, ghip_wg(ctx)), ghip_wg(ctx), 0, ctx->stream>>>(
+      ts, P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), P<SphNode>(t.mq));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
@@ -716,6 +719,10 @@ __global__ void __launch_bounds__(64) k_sel_scatter(int n, const int *__restrict
 
 int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
 {
+  // the first phase of a step that modifies persistent state (smoothing lengths): an asynchronously
+  // built tree is verified first.  The host waits for the build's counting stage only; normally it
+  // is long over, and the gravity walks keep running underneath.
+  GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_finish_gas_tree(ctx));
   if(ctx->gas_wait_upload)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: ghip_upload_aos_particles was not followed by "
@@ -739,7 +746,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 4;
   int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
   HIPCHK(hipMemsetAsync(counter, 0, 8, st));
-  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  HIPCHK(hipEventRecord(ctx->evp[6], st));
 
   int *cur = P<int>(ctx->dtgt_a), *nxt = P<int>(ctx->dtgt_b);
   HIPCHK(hipMemcpyAsync(cur, P<int>(ctx->tg_gas) + lo, (size_t) nt * 4, hipMemcpyDeviceToDevice,
@@ -762,7 +769,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
       const int nbk = (ncur + tgw - 1) / tgw;
       int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
       nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
-      SPH_LAUNCH(k_density, tgw, nbk * nsub, st, t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), ncur,
+      SPH_LAUNCH(k_density, tgw, nbk * nsub, st, P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp), ncur,
                  nsub, cur, hcur, b, P<double>(ctx->drho), P<double>(ctx->dnumngb),
                  P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), counter);
       k_dens_finalize<<<cdiv(ncur, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
@@ -783,7 +790,8 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
       k_sel_scan<<<1, 64, 0, st>>>(nblk, seloff, dnum);
       int left = 0;
       HIPCHK(hipMemcpyAsync(&left, dnum, 4, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
+      GCHK(ghip_check_device_errors(ctx));   // (also what an asynchronous drift / kick deferred)
       if(left > 0)
         {
           k_sel_scatter<<<nblk, 64, 0, st>>>(ncur, cur, P<int>(ctx->dflags), seloff, nxt);
@@ -802,7 +810,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
                              "(reference: endrun(1155), density.c:669-674)", ncur, maxiter);
         }
     }
-  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  HIPCHK(hipEventRecord(ctx->evp[7], st));
   S.dens_iterations = iter;
   return GHIP_OK;
 }
@@ -818,6 +826,7 @@ extern "C" int ghip_update_hmax(ghip_ctx *ctx)
 {
   if(!ctx)
     return GHIP_EINVAL;
+  GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_update_hmax: no tree");
@@ -844,13 +853,13 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   const int nsub = 1;
   int s = 0;
   HIPCHK(hipMemcpyAsync(&s, P<int>(t.iperm) + target, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   int *cur = P<int>(ctx->dtgt_a);
   HIPCHK(hipMemcpyAsync(cur, &s, 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
-  k_density<8><<<nsub, 64, 0, st>>>(t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
+  k_density<8><<<nsub, 64, 0, st>>>(P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
                               P<double>(ctx->drho), P<double>(ctx->dnumngb),
                               P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot),
                               counter);
@@ -866,7 +875,7 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   for(int c = 0; c < 3; c++)
     HIPCHK(hipMemcpyAsync(part[4 + c], P<double>(ctx->drot) + (size_t) c * nsub,
                           (size_t) nsub * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   for(int c = 0; c < 7; c++)
     {
       double acc = 0;
@@ -874,7 +883,7 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
         acc += part[c][q];
       out7[c] = acc;
     }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 
@@ -950,12 +959,12 @@ extern "C" int ghip_ngb_treefind(ghip_ctx *ctx, const double center[3], double h
                                hsml, pairs, b, cap, dlist, dcount);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(nfound, dcount, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   int ncopy = *nfound < cap ? *nfound : cap;
   if(ncopy > 0)
     {
       HIPCHK(hipMemcpyAsync(ngblist, dlist, (size_t) ncopy * 4, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(ghip_stream_sync(ctx, st));
     }
   return GHIP_OK;
 }
@@ -1078,7 +1087,7 @@ __device__ __forceinline__ void d_hydro_pair(const double *r8, const double *q8,
 // pruning uses max(hmax_node, h_i) like ngb_treefind_pairs (ngb.c:136).  Outputs: [5][nt] planes.
 template <int TG>
 __global__ void __launch_bounds__(64)
-k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__ gp,
+k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, const double *__restrict__ gp,
         const double *__restrict__ gq, int nt, int nsub, const int *__restrict__ tgt, BoxK b, HydK K,
         double *__restrict__ part, unsigned long long *__restrict__ counter)
 {
@@ -1121,6 +1130,7 @@ k_hydro(int nelem, const SphNode *__restrict__ nodes, const double *__restrict__
   HydAcc A = {0, 0, 0, 0, 0, 0};
   const BucketBox BB = d_bucket_box(valid, T.px, T.py, T.pz, T.h_i, b);
 
+  const int nelem = __builtin_amdgcn_readfirstlane(ts->nelem);
   int e = 0;
   while(e < nelem)
     {
@@ -1248,6 +1258,7 @@ __global__ void k_hydro_combine(int nt, int nsub, const int *__restrict__ tgt,
 
 int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
 {
+  GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_finish_gas_tree(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_hydro: call ghip_tree_build first");
@@ -1285,17 +1296,17 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
       else
         HIPCHK(hipStreamWaitValue32(st, ctx->pair_started, 1, hipStreamWaitValueGte, 0xffffffffu));
     }
-  HIPCHK(hipEventRecord(ctx->ev[10], st));
+  HIPCHK(hipEventRecord(ctx->evp[10], st));
   const int tgw = ghip_sph_tg();
   const int nbk = (nt + tgw - 1) / tgw;
   int nsub = (ghip_sph_target_waves() + nbk - 1) / nbk;
   nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
   GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
-  SPH_LAUNCH(k_hydro, tgw, nbk * nsub, st, t.nelem, P<SphNode>(t.mq), P<double>(ctx->gp),
+  SPH_LAUNCH(k_hydro, tgw, nbk * nsub, st, P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp),
              P<double>(ctx->gq), nt, nsub, P<int>(ctx->tg_gas) + lo, b, K, P<double>(ctx->hpart),
              counter);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[11], st));
+  HIPCHK(hipEventRecord(ctx->evp[11], st));
   k_hydro_combine<<<cdiv(nt, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
     nt, nsub, P<int>(ctx->tg_gas) + lo, P<int>(t.perm), P<double>(ctx->gq),
     P<double>(ctx->hpart), K, ng, P<double>(ctx->f[GHIP_F_HYDROACCEL]),

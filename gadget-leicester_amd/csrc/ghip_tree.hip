@@ -95,7 +95,7 @@ extern "C" int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const
   k_peano_from_ints<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, dx, dy, dz, bits, dk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(keys, dk, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   return GHIP_OK;
 }
 
@@ -118,7 +118,7 @@ extern "C" int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y
   k_morton_from_ints<<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, dx, dy, dz, bits, dk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(keys, dk, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   return GHIP_OK;
 }
 
@@ -195,7 +195,8 @@ __global__ void k_node_counts(int n, const int *__restrict__ cpl, const int *__r
 
 // one thread per particle: emits the nodes that START at this particle (levels cprev+1..c_i, in
 // increasing depth = pre-order) followed by the particle itself.
-__global__ void k_emit_elements(int n, int nelem, const unsigned long long *__restrict__ skey,
+__global__ void k_emit_elements(int n, const TreeSizes *__restrict__ ts,
+                                const unsigned long long *__restrict__ skey,
                                 const int *__restrict__ cpl, const int *__restrict__ cnt,
                                 const int *__restrict__ nb, const double *__restrict__ px,
                                 const double *__restrict__ py, const double *__restrict__ pz,
@@ -206,7 +207,8 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
                                 const int *__restrict__ slvl)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
+  const int nelem = ts->nelem;   // 0: the counting stage found the tree unusable (TreeSizes.bad)
+  if(i >= n || nelem == 0)
     return;
   int cprev = (i > 0) ? cpl[i - 1] : -1;
   int ci = cpl[i];
@@ -304,22 +306,16 @@ __global__ void k_emit_elements(int n, int nelem, const unsigned long long *__re
   aux[pe] = paux[i];
 }
 
-// multipole pass of one level (force_update_node_recursive, forcetree.c:468-872): children are
-// the elements reached from e+1 by following skip links until the node's own skip.
+// multipole pass (force_update_node_recursive, forcetree.c:468-872): the children of node e are the
+// elements reached from e+1 by following skip links until the node's own skip, summed in that
+// (octant) order.
 // GRAV: aux = largest ForceSoftening below, negated when the node mixes softenings
 //       (BITFLAG_MAX_SOFTENING_TYPE / BITFLAG_MIXED_SOFTENINGS_IN_NODE, forcetree.c:612-700)
 // GAS : aux = hmax (Extnodes[].hmax, forcetree.c:593, 676)
 template <bool GRAV, bool MOMENTS>
-__global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
-                             const double4 *__restrict__ cl, const int4 *__restrict__ lk,
-                             double *__restrict__ aux, bool adaptive)
+__device__ __forceinline__ void d_node_moments(int e, const int4 me, double4 *xm, const double4 *cl,
+                                               const int4 *lk, double *aux, bool adaptive)
 {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
-    return;
-  int4 me = lk[e];
-  if(me.y != -(level + 1))
-    return;
   double mass = 0, sx = 0, sy = 0, sz = 0;
   double amax = 0;
   bool aset = false, mixed = false;
@@ -380,6 +376,98 @@ __global__ void k_node_level(int nelem, int level, double4 *__restrict__ xm,
   // ADAPTIVE_GRAVSOFT_FORGAS: NODE.maxsoft opens the node for every target inside it, mixed or not
   // (forcetree.c:2125-2139)
   aux[e] = (GRAV && (mixed || adaptive)) ? -amax : amax;
+}
+
+// The bottom-up pass in TWO launches (the level-by-level form took one launch per tree level: ~10
+// dependent launches per tree and pass, each reading the links of every element).  The element list
+// is in pre-order, so a node's subtree is the contiguous range [e, skip).
+//   k_moments_local: a workgroup owns a chunk of MOM_CH consecutive elements.  Every node whose
+//     subtree ends inside the chunk -- all but a few thousand -- has all its descendants in the chunk:
+//     the workgroup computes them level by level, deepest first, with a barrier between levels.  The
+//     nodes that reach beyond their chunk (the ancestors of the chunk boundaries) are appended to
+//     per-level lists.
+//   k_moments_upper: ONE workgroup takes those lists level by level, deepest first.
+// Children are summed in list (octant) order as ever, so the numbers are those of the level passes.
+#define MOM_CH 2048
+#define MOM_LEVELS (GHIP_BITS + 1)
+
+// BLOCK: 256 threads, or one wavefront for a pass that runs underneath a gravity pair (ghip_wg)
+template <bool GRAV, bool MOMENTS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_moments_local(const TreeSizes *__restrict__ ts, double4 *xm, const double4 *cl, const int4 *lk,
+                double *aux, bool adaptive, int *__restrict__ upper, int ucap, int *__restrict__ ucount)
+{
+  const int nelem = ts->nelem;
+  const int c0 = blockIdx.x * MOM_CH;
+  if(c0 >= nelem)
+    return;
+  const int c1 = (c0 + MOM_CH < nelem) ? c0 + MOM_CH : nelem;
+  __shared__ unsigned int levels;           // levels at which this chunk owns nodes
+  __shared__ signed char lev[MOM_CH];       // level of the node this chunk owns at each slot, -1: none
+  if(threadIdx.x == 0)
+    levels = 0;
+  __syncthreads();
+  for(int q = threadIdx.x; q < MOM_CH; q += BLOCK)
+    {
+      const int e = c0 + q;
+      int mine = -1;
+      if(e < c1)
+        {
+          const int4 k = lk[e];
+          if(k.y < 0 && k.y >= -MOM_LEVELS)   // a node of level -k.y - 1 (not a particle, not a pruned leaf)
+            {
+              const int L = -k.y - 1;
+              if(k.x > c1)
+                {
+                  const int slot = atomicAdd(&ucount[L], 1);
+                  if(slot < ucap)
+                    upper[L * ucap + slot] = e;
+                }
+              else
+                {
+                  mine = L;
+                  atomicOr(&levels, 1u << L);
+                }
+            }
+        }
+      lev[q] = (signed char) mine;
+    }
+  __syncthreads();
+  unsigned int todo = levels;
+  while(todo)
+    {
+      const int L = 31 - __clz(todo);   // deepest level first
+      todo &= ~(1u << L);
+      for(int q = threadIdx.x; q < MOM_CH; q += BLOCK)
+        if(lev[q] == L)
+          d_node_moments<GRAV, MOMENTS>(c0 + q, lk[c0 + q], xm, cl, lk, aux, adaptive);
+      __threadfence_block();
+      __syncthreads();
+    }
+}
+
+template <bool GRAV, bool MOMENTS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_moments_upper(const TreeSizes *__restrict__ ts, double4 *xm, const double4 *cl, const int4 *lk,
+                double *aux, bool adaptive, const int *__restrict__ upper, int ucap, int *ucount)
+{
+  const bool usable = ts->nelem > 0;
+  for(int L = GHIP_BITS; L >= 0; L--)
+    {
+      const int nu = ucount[L];   // (the same for every thread: the branch is uniform)
+      if(nu == 0 || !usable)
+        continue;
+      for(int k = threadIdx.x; k < nu && k < ucap; k += BLOCK)
+        {
+          const int e = upper[L * ucap + k];
+          d_node_moments<GRAV, MOMENTS>(e, lk[e], xm, cl, lk, aux, adaptive);
+        }
+      __threadfence_block();
+      __syncthreads();
+    }
+  __syncthreads();
+  if(threadIdx.x < MOM_LEVELS)   // the lists are left empty for the next pass
+    ucount[threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -577,13 +665,23 @@ __global__ void k_gather5(int n, const int *__restrict__ perm, const double *__r
   iperm[i] = s;
 }
 
-// out[0] = deepest level, out[1] = number of nodes, out[2] = longest unsorted key run
+// the sizes of the tree, to the device and to the pinned host mirror (TreeSizes): dinfo[0] = deepest
+// level, dinfo[1] = longest key run the 32-bit sort left unsorted
 __global__ void k_tree_info(int n, const int *__restrict__ nb, const int *__restrict__ cnt,
-                            const int *__restrict__ dinfo, int *__restrict__ out)
+                            const int *__restrict__ dinfo, int cap_nodes, int wide, int gen,
+                            TreeSizes *__restrict__ dsz, TreeSizes *__restrict__ hsz)
 {
-  out[0] = dinfo[0];
-  out[1] = nb[n - 1] + cnt[n - 1];
-  out[2] = dinfo[1];
+  TreeSizes s;
+  s.nnodes = nb[n - 1] + cnt[n - 1];
+  s.maxlevel = dinfo[0];
+  s.longrun = dinfo[1];
+  s.bad = (s.nnodes > cap_nodes) ? 1 : ((!wide && s.longrun != 0) ? 2 : 0);
+  s.nelem = s.bad ? 0 : n + s.nnodes;
+  s.n = n;
+  s.gen = gen;
+  s.pad = 0;
+  *dsz = s;
+  *hsz = s;
 }
 
 // gas flags in gravity-tree order (gas = host index below ngas)
@@ -741,9 +839,10 @@ static int gas_order_from_gravity_tree(ghip_ctx *ctx)
   return GHIP_OK;
 }
 
-// common prefix levels, nodes per particle and their scan; {maxlevel, nnodes, longest run} -> hout
+// common prefix levels, nodes per particle and their scan; the tree's sizes -> t.dsz (device) and
+// t.hsz (pinned host mirror).  cap_nodes: nodes the element buffers hold (more: TreeSizes.bad = 1).
 // src_lvl (multi-GPU): levels of the imported pruned nodes in source order, gathered to sorted order
-static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout,
+static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int cap_nodes, bool wide,
                        const int *src_lvl = nullptr)
 {
   hipStream_t st = ctx->stream;
@@ -764,47 +863,116 @@ static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int *hout,
                                               ghip_errword(ctx, GHIP_ERRW_TREE));
   HIPCHK(hipGetLastError());
   GCHK(exclusive_sum(ctx, P<int>(t.cnt), P<int>(t.nb), n));
-  k_tree_info<<<1, 1, 0, st>>>(n, P<int>(t.nb), P<int>(t.cnt), dinfo, hout);
+  k_tree_info<<<1, 1, 0, st>>>(n, P<int>(t.nb), P<int>(t.cnt), dinfo, cap_nodes, wide ? 1 : 0,
+                               ctx->build_gen, P<TreeSizes>(t.dsz), t.hsz);
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
 
-// element list + moments.  Sorted particle data goes to ox,oy,oz,om,oa; iperm is filled too.
-static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const int *hinfo, const double *x,
-                     const double *y, const double *z, const double *m, const double *aux,
-                     double *ox, double *oy, double *oz, double *om, double *oa, bool grav,
+// element buffers of a tree of n sources for up to cap_nodes nodes (one padding record: the walks
+// touch e+1 and the skip link of every element they load)
+static int tree_ensure_elements(ghip_ctx *ctx, TreeDev &t, int n, int cap_nodes)
+{
+  const size_t ce = (size_t) n + (size_t) cap_nodes + 1;
+  GCHK(ghip_ensure(ctx, t.xm, ce * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, t.cl, ce * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, t.lk, ce * sizeof(int4)));
+  GCHK(ghip_ensure(ctx, t.aux, ce * sizeof(double)));
+  // per-level lists of the nodes that reach beyond their chunk (k_moments_local), and their counts
+  const size_t ucap = ce / MOM_CH + 2;
+  GCHK(ghip_ensure(ctx, t.father, ucap * MOM_LEVELS * 4));
+  const size_t before = t.arrived.cap;
+  GCHK(ghip_ensure(ctx, t.arrived, MOM_LEVELS * 4));
+  if(t.arrived.cap != before)   // the counts start at zero and every pass leaves them at zero
+    HIPCHK(hipMemsetAsync(t.arrived.p, 0, t.arrived.cap, ctx->stream));
+  t.cap_nodes = cap_nodes;
+  return GHIP_OK;
+}
+
+// what the counting stage found, taken over by the host (after ev_sizes): exact node count, deepest
+// level; the buffers grow when the count demands it (with slack: the next builds of the same particle
+// set then run without the host waiting for their counts)
+static int tree_adopt_sizes(ghip_ctx *ctx, TreeDev &t, bool grow)
+{
+  TreeSizes z;   // (the mirror is written by the device: read it field by field, not cached)
+  {
+    const volatile int *v = reinterpret_cast<const volatile int *>(t.hsz);
+    int *w = reinterpret_cast<int *>(&z);
+    for(size_t q = 0; q < sizeof(TreeSizes) / sizeof(int); q++)
+      w[q] = v[q];
+  }
+  if(z.gen != ctx->build_gen || z.n != t.n)
+    return ghip_fail(ctx, GHIP_EDEVICE, "tree sizes of build %d expected, the device reported build %d "
+                     "(%d sources for %d)", ctx->build_gen, z.gen, z.n, t.n);
+  t.nnodes = z.nnodes;
+  t.nelem = t.n + z.nnodes;
+  t.maxlevel = z.maxlevel < GHIP_BITS ? z.maxlevel : GHIP_BITS;
+  if(z.bad == 0)
+    {
+      t.last_n = t.n;
+      t.last_nnodes = z.nnodes;
+    }
+  if(grow)
+    {
+      // (always: the buffers hold n + cap_nodes elements, and the number of sources changes too --
+      // a shard's merged tree has more of them than its own tree)
+      int cap = t.cap_nodes;
+      if(cap < z.nnodes + z.nnodes / 16 + 256)
+        cap = z.nnodes + z.nnodes / 4 + 4096;
+      GCHK(tree_ensure_elements(ctx, t, t.n, cap));
+    }
+  return GHIP_OK;
+}
+
+template <bool GRAV, bool MOMENTS>
+static int moment_pass(ghip_ctx *ctx, TreeDev &t, bool adaptive)
+{
+  hipStream_t st = ctx->stream;
+  const size_t ce = (size_t) t.n + (size_t) t.cap_nodes + 1;
+  const int ucap = (int) (ce / MOM_CH + 2);
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
+  const int nblk = cdiv((long long) ce, MOM_CH);
+#define MOM_ARGS ts, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), adaptive, \
+                 P<int>(t.father), ucap, P<int>(t.arrived)
+  if(ctx->grav_pending)
+    {
+      // underneath a gravity pair: one-wavefront workgroups (see ghip_wg)
+      k_moments_local<GRAV, MOMENTS, 64><<<nblk, 64, 0, st>>>(MOM_ARGS);
+      k_moments_upper<GRAV, MOMENTS, 64><<<1, 64, 0, st>>>(MOM_ARGS);
+    }
+  else
+    {
+      k_moments_local<GRAV, MOMENTS, 256><<<nblk, 256, 0, st>>>(MOM_ARGS);
+      k_moments_upper<GRAV, MOMENTS, 1024><<<1, 1024, 0, st>>>(MOM_ARGS);
+    }
+#undef MOM_ARGS
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+// element list + moments.  Sorted particle data goes to ox,oy,oz,om,oa; iperm is filled too.  Grids
+// are sized by the buffers' capacity, the kernels read the element count on the device.
+static int emit_tree(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
+                     const double *z, const double *m, const double *aux, double *ox, double *oy,
+                     double *oz, double *om, double *oa, bool grav,
                      hipEvent_t *fork_after_gather = nullptr, const int *slvl = nullptr)
 {
   hipStream_t st = ctx->stream;
-  t.n = n;
-  t.nnodes = hinfo[1];
-  t.nelem = n + t.nnodes;
-  t.maxlevel = hinfo[0] < GHIP_BITS ? hinfo[0] : GHIP_BITS;
-  GCHK(ghip_ensure(ctx, t.xm, (size_t) t.nelem * sizeof(double4)));
-  GCHK(ghip_ensure(ctx, t.cl, (size_t) t.nelem * sizeof(double4)));
-  GCHK(ghip_ensure(ctx, t.lk, (size_t) t.nelem * sizeof(int4)));
-  GCHK(ghip_ensure(ctx, t.aux, (size_t) t.nelem * sizeof(double)));
-  k_gather5<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
-                                          P<int>(t.iperm));
+  const int wg = ghip_wg(ctx);
+  const int ce = n + t.cap_nodes;
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
+  k_gather5<<<cdiv(n, wg), wg, 0, st>>>(n, P<int>(t.perm), x, y, z, m, aux, ox, oy, oz, om, oa,
+                                        P<int>(t.iperm));
   if(fork_after_gather)
     HIPCHK(hipEventRecord(*fork_after_gather, st));
-  k_emit_elements<<<cdiv(n, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-    n, t.nelem, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
+  k_emit_elements<<<cdiv(n, wg), wg, 0, st>>>(
+    n, ts, P<unsigned long long>(t.skey), P<int>(t.cpl), P<int>(t.cnt), P<int>(t.nb), ox, oy,
     oz, om, oa, ctx->center[0], ctx->center[1], ctx->center[2], ctx->dlen, P<double4>(t.xm),
     P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), slvl);
   HIPCHK(hipGetLastError());
-  for(int L = t.maxlevel; L >= 0; L--)
-    {
-      if(grav)
-        k_node_level<true, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux),
-          ctx->adaptive_gravsoft);
-      else
-        k_node_level<false, true><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-          t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), false);
-    }
-  HIPCHK(hipGetLastError());
-  return GHIP_OK;
+  if(grav)
+    return moment_pass<true, true>(ctx, t, ctx->adaptive_gravsoft);
+  return moment_pass<false, true>(ctx, t, false);
 }
 
 // Peano-Hilbert order of the tree-order particles: the order in which targets are bucketed.
@@ -930,7 +1098,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   const bool dd = ctx->dd.on;
   const int nimp = dd ? ctx->dd.gt_nimp : 0;
   const int nsrc = n + nimp;
-  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  HIPCHK(hipEventRecord(ctx->evp[0], st));
   tree_reset(ctx->gt, nsrc);
   tree_reset(ctx->st, dd ? 0 : ng);
   if(dd)
@@ -940,10 +1108,9 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   ctx->stats.tree_nodes = ctx->stats.gastree_nodes = 0;
   if(nsrc == 0)
     {
-      HIPCHK(hipEventRecord(ctx->ev[1], st));
+      HIPCHK(hipEventRecord(ctx->evp[1], st));
       return GHIP_OK;
     }
-  int *hinfo = reinterpret_cast<int *>(ctx->pinned);  // [0..2] gravity tree, [4..6] gas tree
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
 
   // per-particle softening in host order (aux of the gravity tree's particle elements)
@@ -983,21 +1150,67 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       src_lvl = P<int>(D.src_lvl);
     }
 
-  bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
+  // Asynchronous build: the particle number is the last verified build's, so the element buffers
+  // already hold that build's nodes with slack.  Everything below is enqueued without waiting for the
+  // counts; ghip_tree_verify checks them later (see ghip_internal.h).  Otherwise -- a first build, a
+  // changed particle number, multi-GPU shards whose imports change every step -- the host waits for
+  // the counting stage once (ev_sizes) and sizes the buffers exactly.
+  const bool use_gas = ng > 0 && !dd;
+  TreeDev &G = ctx->gt, &S = ctx->st;
+  bool async = ctx->tree_async_ok && !dd && !ctx->in_recover && G.last_n == nsrc && G.cap_nodes > 0 &&
+               (!use_gas || (S.last_n == ng && S.cap_nodes > 0));
+  if(async)
+    {
+      // (when the last verified count has eaten most of the slack: grow now rather than fail the build)
+      GCHK(tree_ensure_elements(ctx, G, nsrc, G.last_nnodes + G.last_nnodes / 16 + 256 > G.cap_nodes
+                                                ? G.last_nnodes + G.last_nnodes / 4 + 4096
+                                                : G.cap_nodes));
+      if(use_gas)
+        GCHK(tree_ensure_elements(ctx, S, ng, S.last_nnodes + S.last_nnodes / 16 + 256 > S.cap_nodes
+                                                ? S.last_nnodes + S.last_nnodes / 4 + 4096
+                                                : S.cap_nodes));
+    }
+  ctx->build_gen++;
+  ctx->grav_log.clear();
+  ctx->tree_unverified = false;
+  bool wide = ctx->sort_wide || (getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1);
   for(;;)
     {
       HIPCHK(hipMemsetAsync(tree_dinfo(ctx, false), 0, 16, st));
-      GCHK(sort_by_key(ctx, ctx->gt, nsrc, x, y, z, wide, n, given_keys));
-      GCHK(count_nodes(ctx, ctx->gt, nsrc, false, hinfo, src_lvl));
-      if(ng > 0 && !dd)
+      GCHK(sort_by_key(ctx, G, nsrc, x, y, z, wide, n, given_keys));
+      GCHK(count_nodes(ctx, G, nsrc, false, async ? G.cap_nodes : 0x7fffffff, wide, src_lvl));
+      if(use_gas)
         {
           GCHK(gas_order_from_gravity_tree(ctx));
-          GCHK(count_nodes(ctx, ctx->st, ng, true, hinfo + 4));
+          GCHK(count_nodes(ctx, S, ng, true, async ? S.cap_nodes : 0x7fffffff, wide));
         }
-      HIPCHK(hipStreamSynchronize(st));   // the one host round trip of the build
-      if(wide || hinfo[2] == 0)
+      HIPCHK(hipEventRecord(ctx->ev_sizes, st));
+      if(async)
         break;
-      wide = true;   // strongly clustered input: long runs of equal top key bits, sort full keys
+      HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes));   // the one host round trip of a synchronous build
+      const bool longrun = G.hsz->bad == 2 || (use_gas && S.hsz->bad == 2);
+      if(wide || !longrun)
+        break;
+      wide = true;   // strongly clustered input: long runs of equal top key bits, sort full keys ...
+      ctx->sort_wide = true;   // ... from now on
+    }
+  if(async)
+    {
+      // host copies: the last verified build's, until ghip_tree_verify brings this build's
+      G.nnodes = G.last_nnodes;
+      G.nelem = nsrc + G.nnodes;
+      if(use_gas)
+        {
+          S.nnodes = S.last_nnodes;
+          S.nelem = ng + S.nnodes;
+        }
+      ctx->tree_unverified = true;
+    }
+  else
+    {
+      GCHK(tree_adopt_sizes(ctx, G, true));
+      if(use_gas)
+        GCHK(tree_adopt_sizes(ctx, S, true));
     }
 
   GCHK(ghip_ensure(ctx, ctx->sx, (size_t) nsrc * 8));
@@ -1005,13 +1218,13 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->sz, (size_t) nsrc * 8));
   GCHK(ghip_ensure(ctx, ctx->gt.iperm, (size_t) nsrc * 4));
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsrc * 5 * sizeof(double)));
-  GCHK(emit_tree(ctx, ctx->gt, nsrc, hinfo, x, y, z, m, tmp_soft, P<double>(ctx->sx),
+  GCHK(emit_tree(ctx, ctx->gt, nsrc, x, y, z, m, tmp_soft, P<double>(ctx->sx),
                  P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->stage),
                  P<double>(ctx->ssoft), true, &ctx->evt[0],
                  src_lvl ? P<int>(ctx->gt.slvl) : nullptr));
   ctx->gt.built = true;
   // The curve order of the targets needs the tree-order positions only (the gather at the head of
-  // emit_tree): it runs on a second stream next to the element emission, the moment passes and the
+  // emit_tree): it runs on a second stream next to the element emission, the moment pass and the
   // walk records.  Both chains are strings of short launches, so side by side they take the longer
   // of the two instead of the sum.
   // (the main stream's remaining launches are enqueued first: the host needs longer to enqueue the
@@ -1026,16 +1239,10 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   // counts and curve order are known; the rest of its build is deferred to the first call that
   // needs it (ghip_finish_gas_tree), which normally is ghip_density -- enqueued while a gravity
   // pair is in flight, so that this work runs underneath the walks.
-  if(ng > 0 && !dd)
-    {
-      for(int q = 0; q < 3; q++)
-        ctx->gas_hinfo[q] = hinfo[4 + q];
-      ctx->st.nnodes = hinfo[5];
-      ctx->st.nelem = ng + hinfo[5];
-      ctx->gas_pending = true;
-    }
+  if(use_gas)
+    ctx->gas_pending = true;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  HIPCHK(hipEventRecord(ctx->evp[1], st));
   ctx->stats.tree_nodes = ctx->gt.nnodes;
   ctx->stats.gastree_nodes = ctx->st.nnodes;
   return GHIP_OK;
@@ -1153,22 +1360,25 @@ int ghip_dd_build_gas_tree(ghip_ctx *ctx)
     ng, nghost, n, P<double>(ctx->f[GHIP_F_POS]), P<double>(ctx->f[GHIP_F_MASS]),
     P<double>(ctx->f[GHIP_F_HSML]), P<GhostRec>(D.gh_recv), gx, gy, gz, gm, gh);
   HIPCHK(hipGetLastError());
-  int *hinfo = reinterpret_cast<int *>(ctx->pinned) + 4;
-  bool wide = getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1;
+  // (a shard's ghosts change every step: synchronous sizes, like the shard's gravity trees)
+  ctx->build_gen++;
+  bool wide = ctx->sort_wide || (getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1);
   for(;;)
     {
       HIPCHK(hipMemsetAsync(tree_dinfo(ctx, true), 0, 8, st));
       GCHK(sort_by_key(ctx, t, nsg, gx, gy, gz, wide, -1, nullptr, true));
-      GCHK(count_nodes(ctx, t, nsg, true, hinfo));
-      HIPCHK(hipStreamSynchronize(st));
-      if(wide || hinfo[2] == 0)
+      GCHK(count_nodes(ctx, t, nsg, true, 0x7fffffff, wide));
+      HIPCHK(ghip_stream_sync(ctx, st));
+      if(wide || t.hsz->bad != 2)
         break;
       wide = true;
+      ctx->sort_wide = true;
     }
+  GCHK(tree_adopt_sizes(ctx, t, true));
   GCHK(ghip_ensure(ctx, t.iperm, (size_t) nsg * 4));
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nsg * 5 * sizeof(double)));
   double *s = P<double>(ctx->stage);
-  GCHK(emit_tree(ctx, t, nsg, hinfo, gx, gy, gz, gm, gh, s, s + nsg, s + 2 * (size_t) nsg,
+  GCHK(emit_tree(ctx, t, nsg, gx, gy, gz, gm, gh, s, s + nsg, s + 2 * (size_t) nsg,
                  s + 3 * (size_t) nsg, s + 4 * (size_t) nsg, false));
   t.built = true;
   GCHK(ghip_sph_fill_nodes(ctx, false));
@@ -1243,7 +1453,7 @@ int ghip_finish_gas_tree(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) ng * 5 * sizeof(double)));
   double *s = P<double>(ctx->stage);
-  GCHK(emit_tree(ctx, ctx->st, ng, ctx->gas_hinfo, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
+  GCHK(emit_tree(ctx, ctx->st, ng, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
                  s + 3 * (size_t) ng, s + 4 * (size_t) ng, false));
   ctx->st.built = true;
   GCHK(ghip_sph_fill_nodes(ctx, false));
@@ -1262,11 +1472,11 @@ int ghip_finish_gas_tree(ghip_ctx *ctx)
 
 // refresh Extnodes[].hmax of the gas tree from the current smoothing lengths in gp[].h
 // (force_update_hmax, forcetree.c:1661-1786; recomputed exactly instead of only raised)
-__global__ void k_aux_from_gp(int nelem, const int4 *__restrict__ lk,
+__global__ void k_aux_from_gp(const TreeSizes *__restrict__ ts, const int4 *__restrict__ lk,
                               const double *__restrict__ gp, double *__restrict__ aux)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
+  if(e >= ts->nelem)
     return;
   int4 me = lk[e];
   if(me.y >= 0)
@@ -1279,15 +1489,62 @@ int ghip_gastree_refresh_hmax(ghip_ctx *ctx)
   if(t.n == 0)
     return GHIP_OK;
   hipStream_t st = ctx->stream;
-  HIPCHK(hipEventRecord(ctx->ev[8], st));
-  k_aux_from_gp<<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(t.nelem, P<int4>(t.lk), P<double>(ctx->gp),
-                                                   P<double>(t.aux));
-  for(int L = t.maxlevel; L >= 0; L--)
-    k_node_level<false, false><<<cdiv(t.nelem, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-      t.nelem, L, P<double4>(t.xm), P<double4>(t.cl), P<int4>(t.lk), P<double>(t.aux), false);
+  const int wg = ghip_wg(ctx), ce = t.n + t.cap_nodes;
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
+  HIPCHK(hipEventRecord(ctx->evp[8], st));
+  k_aux_from_gp<<<cdiv(ce, wg), wg, 0, st>>>(ts, P<int4>(t.lk), P<double>(ctx->gp), P<double>(t.aux));
   HIPCHK(hipGetLastError());
+  GCHK((moment_pass<false, false>(ctx, t, false)));
   GCHK(ghip_sph_fill_nodes(ctx, true));
-  HIPCHK(hipEventRecord(ctx->ev[9], st));
+  HIPCHK(hipEventRecord(ctx->evp[9], st));
+  return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// verification of an asynchronously built tree (see ghip_internal.h)
+// ---------------------------------------------------------------------------------------------
+static int tree_recover(ghip_ctx *ctx)
+{
+  // Whatever ran on the bad tree did nothing (nelem = 0 on the device).  Drain it, repeat the build
+  // synchronously -- the buffers grow / the sort goes wide as the counts demand -- and replay the
+  // gravity calls made since.
+  ctx->in_recover = true;
+  const std::vector<ghip_ctx::GravCall> log = ctx->grav_log;
+  int r = GHIP_OK;
+  if(hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream2) != hipSuccess ||
+     hipStreamSynchronize(ctx->stream3) != hipSuccess)
+    r = ghip_fail(ctx, GHIP_EHIP, "tree recovery: stream synchronisation failed");
+  ctx->n_syncs += 3;
+  ctx->grav_pending = false;
+  if(ctx->gt.hsz->bad == 2 || (ctx->ngas > 0 && ctx->st.hsz->bad == 2))
+    ctx->sort_wide = true;
+  if(r == GHIP_OK)
+    r = ghip_tree_build_impl(ctx);
+  for(size_t k = 0; r == GHIP_OK && k < log.size(); k++)
+    {
+      if(k > 0)
+        r = ghip_join_pair(ctx);
+      if(r == GHIP_OK)
+        r = ghip_gravity_impl(ctx, &log[k].p, log[k].walk);
+    }
+  ctx->in_recover = false;
+  return r;
+}
+
+int ghip_tree_verify(ghip_ctx *ctx)
+{
+  if(!ctx->tree_unverified)
+    return GHIP_OK;
+  ctx->tree_unverified = false;
+  HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes));   // the counting stage only: the walks may still be running
+  const bool use_gas = ctx->ngas > 0 && !ctx->dd.on;
+  GCHK(tree_adopt_sizes(ctx, ctx->gt, false));
+  if(use_gas)
+    GCHK(tree_adopt_sizes(ctx, ctx->st, false));
+  ctx->stats.tree_nodes = ctx->gt.nnodes;
+  ctx->stats.gastree_nodes = ctx->st.nnodes;
+  if(ctx->gt.hsz->bad != 0 || (use_gas && ctx->st.hsz->bad != 0))
+    return tree_recover(ctx);
   return GHIP_OK;
 }
 
@@ -1342,7 +1599,7 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
   HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cubtmp.p, tb, P<int>(t.phorder),
                                        P<int>(ctx->dtgt_a), P<int>(list), dnum, n, st));
   HIPCHK(hipMemcpyAsync(count, dnum, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
 

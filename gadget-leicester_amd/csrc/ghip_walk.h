@@ -739,7 +739,8 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
             const double *__restrict__ tsoft, const double *__restrict__ toldacc, GravK p,
             const float *__restrict__ srtab, const double *__restrict__ ewtab,
             double *__restrict__ pax, double *__restrict__ pay, double *__restrict__ paz,
-            int *__restrict__ pcost, unsigned long long *__restrict__ counter, WalkPlan plan)
+            int *__restrict__ pcost, unsigned long long *__restrict__ counter,
+            unsigned long long *__restrict__ acc, WalkPlan plan)
 {
   const int lane = threadIdx.x & 63;
   // "every workgroup of this grid has been dispatched": from here on the kernel only drains, and the
@@ -794,11 +795,18 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
       pcost[o] = p.debug_steps ? (int) steps : W.nint;
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) W.nint);
+  // counter: this call's totals (reset by the next call of the kind); acc: the run's (ghip_run_begin),
+  // kept by the kernel itself -- the next call's reset is enqueued on this walk's stream and may
+  // overtake whatever the main stream would do with the counters at the end of a step
   if(lane == 0 && tot)
-    atomicAdd(counter, tot);
+    {
+      atomicAdd(counter, tot);
+      atomicAdd(acc, tot);
+    }
   if(lane == 0)
     {
       atomicAdd(counter + 8, (unsigned long long) steps);
+      atomicAdd(acc + 4, (unsigned long long) steps);
       atomicAdd(plan.steps_out + bucket, steps);   // cost model of the next call's plan
     }
 }
@@ -866,10 +874,11 @@ struct SegTables
   int ns[3], soff[3], noff[3];
 };
 
-__global__ void k_build_segments(int nelem, const int4 *__restrict__ lk, SegTables T,
-                                 int *__restrict__ start, int *__restrict__ nanc,
+__global__ void k_build_segments(const TreeSizes *__restrict__ ts, const int4 *__restrict__ lk,
+                                 SegTables T, int *__restrict__ start, int *__restrict__ nanc,
                                  int *__restrict__ anc)
 {
+  const int nelem = ts->nelem;   // (0 for an unusable tree: every segment is empty then)
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   int j = 0;
   while(j < T.ntab && g > T.ns[j])
@@ -952,13 +961,13 @@ __global__ void k_combine_grav(int nt, WalkPlan plan, const int *__restrict__ tg
 }
 
 // the walk's hot/cold element records from the tree arrays (see WalkHot / WalkCold)
-__global__ void k_fill_elems(int nelem, const double4 *__restrict__ xm,
+__global__ void k_fill_elems(const TreeSizes *__restrict__ ts, const double4 *__restrict__ xm,
                              const double4 *__restrict__ cl, const int4 *__restrict__ lk,
                              const double *__restrict__ aux, WalkHot *__restrict__ hot,
                              WalkCold *__restrict__ cold)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if(e >= nelem)
+  if(e >= ts->nelem)
     return;
   double4 v = xm[e], c = cl[e];
   int4 k = lk[e];

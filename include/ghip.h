@@ -354,10 +354,14 @@ int ghip_drift(ghip_ctx *ctx, const ghip_drift_params *p);
  * (final, xG), HYDROACCEL, HSML, MAXSIGNALVEL, DENSITY, TYPE.  TimeBinCount/TimeBinCountSph
  * (32 entries each, may be NULL) receive the recounted bin populations (allvars.h:337-338).
  * Returns GHIP_ETIMESTEP where the reference calls endrun(); ghip_timestep_endrun_code gives the
- * reference's code (888, 818, 112313). ---- */
+ * reference's code (888, 818, 112313).  With both arrays NULL the bins are not recounted
+ * (ghip_timebin_counts does it on demand) and, under ghip_set_async, the call does not wait. ---- */
 int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p, long long *TimeBinCount,
                            long long *TimeBinCountSph);
 int ghip_timestep_endrun_code(const ghip_ctx *ctx);
+/* the bin populations after the last ghip_advance_timesteps, recounted over all particles
+ * (reconstruct_timebins, predict.c:14-127); synchronises */
+int ghip_timebin_counts(ghip_ctx *ctx, long long *TimeBinCount, long long *TimeBinCountSph);
 int ghip_pm_kick(ghip_ctx *ctx, const ghip_pmkick_params *p);
 /* per-type sums of find_dt_displacement_constraint (timestep.c:1140-1156): sum of |v|^2, smallest
  * positive mass (1e30 if none), particle count -- 6 entries each */
@@ -540,6 +544,43 @@ int ghip_peano_hilbert_keys(ghip_ctx *ctx, int n, const int *x, const int *y, co
                             int bits, unsigned long long *keys);
 int ghip_morton_keys(ghip_ctx *ctx, int n, const int *x, const int *y, const int *z, int bits,
                      unsigned long long *keys);
+
+/* ---- a resident step loop that never waits for the device (run.c:40-155 with P / SphP in HBM) ----
+ * ghip_set_async(ctx, 1): ghip_drift and ghip_advance_timesteps (called with NULL count arrays)
+ * return without waiting; what they would have reported -- the reference's endrun(12) of a particle
+ * ahead of the drift target, endrun(888|818|112313) of a failed timestep criterion -- is reported
+ * with the same codes by the next entry point that synchronises (ghip_sync, ghip_get_field, the
+ * h iteration of ghip_density, ...).  ghip_tree_build needs no switch: whenever the particle number
+ * equals the previous build's it is enqueued without waiting for the node counts, and the counts
+ * are verified before anything persistent is modified on their basis (a build that overflowed its
+ * buffers is repeated and the gravity calls made since are replayed: same results, later).
+ * With both, the host enqueues a step while the device still works on the previous one; the only
+ * wait left in a step with gas is the h iteration's unconverged count, which is read underneath
+ * the gravity walks. */
+int ghip_set_async(ghip_ctx *ctx, int on);
+
+/* statistics of a run of steps without a host synchronisation per step: the library keeps one set
+ * of phase events per step and sums its device counters on the device.
+ *   ghip_run_begin(ctx, max_steps);  { ghip_step_begin(ctx); <the calls of a step>; ghip_step_end(ctx); } ...
+ *   ghip_run_end(ctx, &stats)        -- synchronises once */
+typedef struct
+{
+  long long steps;             /* ghip_step_end calls */
+  long long steps_timed;       /* of them, with events kept (the last max_steps) */
+  long long launches;          /* kernel launches issued by the library (its own and rocPRIM's) */
+  long long blocking_syncs;    /* host waits for the device inside the library */
+  long long grav_interactions, ewald_interactions, dens_neighbours, hydro_pairs;
+  long long grav_wave_steps, ewald_wave_steps, dens_extra_iterations;
+  double ms_tree, ms_grav, ms_ewald, ms_dens, ms_hmax, ms_hydro, ms_kick;   /* summed device spans */
+  double ms_steps_device;      /* sum over steps of (step begin mark -> step end mark), device clock */
+  double ms_between_steps;     /* sum of (end mark of step k -> begin mark of step k+1): the device
+                                * waiting for the host between steps */
+  double ms_first_to_last;     /* begin mark of the first timed step -> end mark of the last */
+} ghip_run_stats;
+int ghip_run_begin(ghip_ctx *ctx, int max_steps);
+int ghip_step_begin(ghip_ctx *ctx);
+int ghip_step_end(ghip_ctx *ctx);
+int ghip_run_end(ghip_ctx *ctx, ghip_run_stats *out);
 
 /* ---- introspection ---- */
 int ghip_get_stats(const ghip_ctx *ctx, ghip_stats *out);
