@@ -109,7 +109,10 @@ int ghip_join(ghip_ctx *ctx)
   if(ctx)
     GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_join_pair(ctx));
-  return ctx ? ghip_finish_gas_tree(ctx) : GHIP_OK;
+  if(!ctx)
+    return GHIP_OK;
+  GCHK(ghip_finish_gas_tree(ctx));
+  return ghip_gas_verify(ctx);
 }
 
 int *ghip_errwords(void)
@@ -210,7 +213,8 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       }
   ctx->ev_ready = true;
   ctx->evp = ctx->ev;
-  if(hipEventCreateWithFlags(&ctx->ev_sizes, hipEventDisableTiming) != hipSuccess)
+  if(hipEventCreateWithFlags(&ctx->ev_sizes, hipEventDisableTiming) != hipSuccess ||
+     hipEventCreateWithFlags(&ctx->ev_sizes_gas, hipEventDisableTiming) != hipSuccess)
     {
       delete ctx;
       return GHIP_EHIP;
@@ -322,6 +326,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
       (void) hipEventDestroy(ctx->ev[i]);
   if(ctx->ev_sizes)
     (void) hipEventDestroy(ctx->ev_sizes);
+  if(ctx->ev_sizes_gas)
+    (void) hipEventDestroy(ctx->ev_sizes_gas);
   for(hipEvent_t e : ctx->ev_ring)
     (void) hipEventDestroy(e);
   free_buf(ctx->run_acc);
@@ -423,7 +429,7 @@ extern "C" int ghip_set_counts(ghip_ctx *ctx, int numpart, int ngas)
       ctx->gt.built = false;
       ctx->st.built = false;
       ctx->nactive = -1;
-      ctx->lists_dirty = true;
+      ctx->lists_dirty = ctx->gas_list_dirty = true;
     }
   return GHIP_OK;
 }
@@ -840,7 +846,7 @@ extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
       if(nactive != 0 && nactive != ctx->n)
         return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_active: NULL list means all particles");
       ctx->nactive = (nactive == 0 && ctx->n != 0) ? -1 : -1;
-      ctx->lists_dirty = true;
+      ctx->lists_dirty = ctx->gas_list_dirty = true;
       return GHIP_OK;
     }
   for(int a = 0; a < nactive; a++)
@@ -854,7 +860,7 @@ extern "C" int ghip_set_active(ghip_ctx *ctx, const int *idx, int nactive)
       HIPCHK(ghip_stream_sync(ctx, ctx->stream));
     }
   ctx->nactive = nactive;
-  ctx->lists_dirty = true;
+  ctx->lists_dirty = ctx->gas_list_dirty = true;
   return GHIP_OK;
 }
 
@@ -866,7 +872,7 @@ extern "C" int ghip_set_shard(ghip_ctx *ctx, int rank, int nranks)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_shard: need 0 <= rank < nranks <= %d",
                      GHIP_MAXRANKS);
   if(nranks != ctx->shard_n)
-    ctx->lists_dirty = true;   // the stored list order is rank-major
+    ctx->lists_dirty = ctx->gas_list_dirty = true;   // the stored list order is rank-major
   ctx->shard_rank = rank;
   ctx->shard_n = nranks;
   return GHIP_OK;

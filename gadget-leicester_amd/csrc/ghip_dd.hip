@@ -1464,7 +1464,7 @@ static int migrate_step(ghip_ctx *ctx)
       ctx->gt.built = false;
       ctx->st.built = false;
       ctx->nactive = -1;
-      ctx->lists_dirty = true;
+      ctx->lists_dirty = ctx->gas_list_dirty = true;
       return GHIP_OK;
     }
   return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: migration has no phase %d", D.phase);

@@ -249,7 +249,8 @@ struct ghip_ctx
   // active lists
   DevBuf act_host_idx;  // i32[nactive] host indices (uploaded)
   int nactive = -1;     // -1: all
-  bool lists_dirty = true;
+  bool lists_dirty = true;       // gravity target list
+  bool gas_list_dirty = true;    // gas target list (made once the deferred gas tree exists)
   DevBuf tg_grav, tg_gas;  // sorted-order target lists
   int nt_grav = 0, nt_gas = 0;
   int shard_rank = 0, shard_n = 1;
@@ -316,7 +317,9 @@ struct ghip_ctx
   bool async = false;              // ghip_set_async: drift / kick report their errors at the next sync
   bool tree_unverified = false;
   bool tree_async_ok = true;       // GHIP_TREE_SYNC=1 switches the asynchronous build off
-  hipEvent_t ev_sizes = nullptr;
+  hipEvent_t ev_sizes = nullptr, ev_sizes_gas = nullptr;
+  bool gas_unverified = false;     // the same for the gas tree, whose whole build is deferred (ghip_finish_gas_tree)
+  bool gas_async = false;          // ... and follows the gravity tree's mode
   int build_gen = 0;
   bool sort_wide = false;          // sticky: a build met key runs too long for the 32-bit sort
   bool in_recover = false;
@@ -351,6 +354,7 @@ static inline hipError_t ghip_event_sync(ghip_ctx *ctx, hipEvent_t e)
 }
 long long ghip_launch_count(void);   // kernel launches issued through this library so far (ghip_api.hip)
 int ghip_tree_verify(ghip_ctx *ctx);  // tree.hip
+int ghip_gas_verify(ghip_ctx *ctx);
 
 int ghip_fail(ghip_ctx *ctx, int code, const char *fmt, ...);
 // Device error words: ints in pinned, device-visible host memory that kernels set when an internal

@@ -727,6 +727,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   if(ctx->gas_wait_upload)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: ghip_upload_aos_particles was not followed by "
                      "ghip_upload_aos_gas");
+  GCHK(ghip_gas_verify(ctx));   // (the gas tree's node count, like the gravity tree's above)
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_density: call ghip_tree_build first");
   GCHK(ghip_build_target_lists(ctx));
@@ -828,6 +829,7 @@ extern "C" int ghip_update_hmax(ghip_ctx *ctx)
     return GHIP_EINVAL;
   GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_finish_gas_tree(ctx));
+  GCHK(ghip_gas_verify(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_update_hmax: no tree");
   return ghip_gastree_refresh_hmax(ctx);
@@ -1260,6 +1262,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
 {
   GCHK(ghip_tree_verify(ctx));
   GCHK(ghip_finish_gas_tree(ctx));
+  GCHK(ghip_gas_verify(ctx));
   if(!ctx->st.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_hydro: call ghip_tree_build first");
   GCHK(ghip_build_target_lists(ctx));

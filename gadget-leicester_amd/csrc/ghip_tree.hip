@@ -170,6 +170,53 @@ __global__ void k_prefix_levels(int n, const unsigned long long *__restrict__ sk
     }
 }
 
+// k_prefix_levels and k_node_counts in one launch: the shared-digit counts with both neighbours come
+// straight from the keys
+__global__ void k_prefix_counts(int n, const unsigned long long *__restrict__ skey,
+                                const int *__restrict__ slvl, int *__restrict__ cpl,
+                                int *__restrict__ cnt, int *__restrict__ maxlevel,
+                                int *__restrict__ errword)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = -1;
+  if(i < n)
+    {
+      const unsigned long long k = skey[i];
+      const int craw = (i + 1 < n) ? d_common_levels(k, skey[i + 1]) : -1;
+      const int cprev = (i > 0) ? d_common_levels(skey[i - 1], k) : -1;
+      cpl[i] = craw;
+      int ceff = craw;
+      if(slvl && slvl[i] > 0)
+        {
+          const int L = slvl[i];   // (see k_node_counts)
+          if(craw >= L || cprev >= L)
+            *(volatile int *) errword = 3;
+          if(L - 1 > ceff)
+            ceff = L - 1;
+        }
+      const int d = ceff - cprev;
+      cnt[i] = d > 0 ? d : 0;
+      c = ceff;
+    }
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      int o = __shfl_xor(c, off, 64);
+      c = o > c ? o : c;
+    }
+  __shared__ int wmax[16];
+  if((threadIdx.x & 63) == 0)
+    wmax[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if(threadIdx.x == 0)
+    {
+      int nw = (blockDim.x + 63) >> 6;
+      for(int w = 1; w < nw; w++)
+        c = wmax[w] > c ? wmax[w] : c;
+      if(c > *(volatile int *) maxlevel)
+        atomicMax(maxlevel, c);
+    }
+}
+
 __global__ void k_node_counts(int n, const int *__restrict__ cpl, const int *__restrict__ slvl,
                               int *__restrict__ cnt, int *__restrict__ errword)
 {
@@ -640,6 +687,35 @@ static int cub_tmp(ghip_ctx *ctx, size_t bytes)
   return ghip_ensure(ctx, ctx->cubtmp, bytes + 256);
 }
 
+// Radix sort of (32-bit key, index) pairs on bits [0, end_bit).  Below 2^20 keys the library picks a
+// block sort followed by ~19 merge passes (~125 us at 5e5 keys, all dependent ~5 us launches).  Its
+// one-sweep radix sort (GHIP_SORT_ONESWEEP=1) needs fewer launches but was measured slower here:
+// a histogram pass, its scan, and per 8-bit digit two clears + one 25 us pass = 157 us.
+// tmp: scratch of the stream the sort runs on (ctx->cubtmp: main stream, ctx->cubtmp2: stream2)
+static int sort_pairs_u32(ghip_ctx *ctx, const unsigned int *kin, unsigned int *kout, const int *vin,
+                          int *vout, int n, int end_bit, hipStream_t st, DevBuf &tmp)
+{
+  static int onesweep = -1;
+  if(onesweep < 0)
+    onesweep = (getenv("GHIP_SORT_ONESWEEP") && atoi(getenv("GHIP_SORT_ONESWEEP")) == 1) ? 1 : 0;
+  size_t tb = 0;
+  if(onesweep && n > 4096)
+    {
+      using cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                             rocprim::default_config, 0>;
+      HIPCHK(rocprim::radix_sort_pairs<cfg>(nullptr, tb, kin, kout, vin, vout, (size_t) n, 0u,
+                                            (unsigned int) end_bit, st));
+      GCHK(ghip_ensure(ctx, tmp, tb + 256));
+      HIPCHK(rocprim::radix_sort_pairs<cfg>(tmp.p, tb, kin, kout, vin, vout, (size_t) n, 0u,
+                                            (unsigned int) end_bit, st));
+      return GHIP_OK;
+    }
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, kout, vin, vout, n, 0, end_bit, st));
+  GCHK(ghip_ensure(ctx, tmp, tb + 256));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin, kout, vin, vout, n, 0, end_bit, st));
+  return GHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // tree construction driver.  The build is latency-bound (dozens of launches of a few us each),
 // so the steps are arranged for few launches and ONE host round trip for both trees:
@@ -668,7 +744,7 @@ __global__ void k_gather5(int n, const int *__restrict__ perm, const double *__r
 // the sizes of the tree, to the device and to the pinned host mirror (TreeSizes): dinfo[0] = deepest
 // level, dinfo[1] = longest key run the 32-bit sort left unsorted
 __global__ void k_tree_info(int n, const int *__restrict__ nb, const int *__restrict__ cnt,
-                            const int *__restrict__ dinfo, int cap_nodes, int wide, int gen,
+                            int *__restrict__ dinfo, int cap_nodes, int wide, int gen,
                             TreeSizes *__restrict__ dsz, TreeSizes *__restrict__ hsz)
 {
   TreeSizes s;
@@ -682,6 +758,7 @@ __global__ void k_tree_info(int n, const int *__restrict__ nb, const int *__rest
   s.pad = 0;
   *dsz = s;
   *hsz = s;
+  dinfo[0] = dinfo[1] = 0;   // (the consumer leaves the words zeroed for the next build: no memset in front of it)
 }
 
 // gas flags in gravity-tree order (gas = host index below ngas)
@@ -745,13 +822,89 @@ __global__ void k_peano_hi(int n, int levels, const double *__restrict__ x,
   idx[i] = i;
 }
 
+// Exclusive scan of ints out of one-wavefront workgroups, for scans that run underneath a gravity
+// pair: the library's single-pass scan uses 256-thread workgroups, which wait behind the walks for
+// four free wavefront slots on one CU (see ghip_wg).  Three launches: per-block sums, their scan by
+// one wavefront, the blocks' local scans.
+#define WSCAN_ITEMS 16
+#define WSCAN_BLOCK (64 * WSCAN_ITEMS)
+__global__ void __launch_bounds__(64) k_wscan_sums(int n, const int *__restrict__ in, int *__restrict__ bsum)
+{
+  const int base = blockIdx.x * WSCAN_BLOCK + threadIdx.x * WSCAN_ITEMS;
+  int c = 0;
+  for(int j = 0; j < WSCAN_ITEMS; j++)
+    c += (base + j < n) ? in[base + j] : 0;
+  for(int o = 32; o > 0; o >>= 1)
+    c += __shfl_down(c, o, 64);
+  if(threadIdx.x == 0)
+    bsum[blockIdx.x] = c;
+}
+
+__global__ void __launch_bounds__(64) k_wscan_blocks(int nblk, int *__restrict__ bsum)
+{
+  int run = 0;
+  for(int b0 = 0; b0 < nblk; b0 += 64)
+    {
+      const int b = b0 + threadIdx.x;
+      const int c = b < nblk ? bsum[b] : 0;
+      int incl = c;
+      for(int o = 1; o < 64; o <<= 1)
+        {
+          const int v = __shfl_up(incl, o, 64);
+          if((int) threadIdx.x >= o)
+            incl += v;
+        }
+      if(b < nblk)
+        bsum[b] = run + incl - c;
+      run += __shfl(incl, 63, 64);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_wscan_apply(int n, const int *__restrict__ in,
+                                                    const int *__restrict__ boff, int *__restrict__ out)
+{
+  const int base = blockIdx.x * WSCAN_BLOCK + threadIdx.x * WSCAN_ITEMS;
+  int v[WSCAN_ITEMS], c = 0;
+  for(int j = 0; j < WSCAN_ITEMS; j++)
+    {
+      v[j] = (base + j < n) ? in[base + j] : 0;
+      c += v[j];
+    }
+  int incl = c;
+  for(int o = 1; o < 64; o <<= 1)
+    {
+      const int u = __shfl_up(incl, o, 64);
+      if((int) threadIdx.x >= o)
+        incl += u;
+    }
+  int run = boff[blockIdx.x] + incl - c;
+  for(int j = 0; j < WSCAN_ITEMS; j++)
+    {
+      if(base + j < n)
+        out[base + j] = run;
+      run += v[j];
+    }
+}
+
 static int exclusive_sum(ghip_ctx *ctx, const int *in, int *out, int n, hipStream_t on = nullptr)
 {
   hipStream_t st = on ? on : ctx->stream;
+  if(ctx->grav_pending && st == ctx->stream)
+    {
+      const int nblk = cdiv(n, WSCAN_BLOCK);
+      GCHK(ghip_ensure(ctx, ctx->cubtmp, (size_t) (nblk + 2) * 4));
+      int *bsum = P<int>(ctx->cubtmp);
+      k_wscan_sums<<<nblk, 64, 0, st>>>(n, in, bsum);
+      k_wscan_blocks<<<1, 64, 0, st>>>(nblk, bsum);
+      k_wscan_apply<<<nblk, 64, 0, st>>>(n, in, bsum, out);
+      HIPCHK(hipGetLastError());
+      return GHIP_OK;
+    }
+  DevBuf &tmp = (st == ctx->stream) ? ctx->cubtmp : ctx->cubtmp2;   // scratch of the stream it runs on
   size_t tb = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, n, st));
-  GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubtmp.p, tb, in, out, n, st));
+  GCHK(ghip_ensure(ctx, tmp, tb + 256));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, n, st));
   return GHIP_OK;
 }
 
@@ -771,9 +924,49 @@ __global__ void k_override_keys(int first, int n, const unsigned long long *__re
     key[i] = given[i];
 }
 
+// hsml != nullptr: ADAPTIVE_GRAVSOFT_FORGAS, a gas particle is softened with its Hsml
+// (forcetree.c:705-716, 1851-1856, 2038-2058)
+__global__ void k_soft_of_type(int n, const int *__restrict__ type, double s0, double s1, double s2,
+                               double s3, double s4, double s5, const double *__restrict__ hsml,
+                               double *__restrict__ out)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int t = type[i];
+  out[i] = (t == 0) ? (hsml ? hsml[i] : s0)
+                    : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+}
+
+// per-particle softening, Morton key, index and the key's top 32 bits in one launch (the head of a
+// single-GPU gravity-tree build: k_soft_of_type + k_morton_from_pos + k_key_hi)
+__global__ void k_keys_fused(int n, const int *__restrict__ type, double s0, double s1, double s2,
+                             double s3, double s4, double s5, const double *__restrict__ hsml,
+                             const double *__restrict__ x, const double *__restrict__ y,
+                             const double *__restrict__ z, double cx, double cy, double cz, double fac,
+                             double *__restrict__ soft, unsigned long long *__restrict__ key,
+                             int *__restrict__ idx, unsigned int *__restrict__ hi)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const int t = type[i];
+  soft[i] = (t == 0) ? (hsml ? hsml[i] : s0) : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+  const int ix = (int) ((x[i] - cx) * fac);   // forcetree.c:181-185
+  const int iy = (int) ((y[i] - cy) * fac);
+  const int iz = (int) ((z[i] - cz) * fac);
+  const unsigned long long k = d_morton21(ix, iy, iz);
+  key[i] = k;
+  idx[i] = i;
+  hi[i] = (unsigned int) (k >> 31);
+}
+
+// type != nullptr (single-GPU gravity tree, 32-bit sort): the softenings (-> soft_out) are formed by the
+// same launch as the keys
 static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const double *y,
                        const double *z, bool wide, int nlocal = -1,
-                       const unsigned long long *given_keys = nullptr, bool gas = false)
+                       const unsigned long long *given_keys = nullptr, bool gas = false,
+                       const int *type = nullptr, double *soft_out = nullptr)
 {
   hipStream_t st = ctx->stream;
   GCHK(ghip_ensure(ctx, t.key, (size_t) n * 8));
@@ -782,9 +975,22 @@ static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const 
   GCHK(ghip_ensure(ctx, t.perm, (size_t) n * 4));
   GCHK(ghip_ensure(ctx, t.phkey, (size_t) n * 8));
   double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);  // DomainFac, domain.c:2012
-  k_morton_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, x, y, z, ctx->corner[0], ctx->corner[1],
-                                                  ctx->corner[2], fac,
-                                                  P<unsigned long long>(t.key), P<int>(t.idx));
+  const bool fused = type && soft_out && !wide && !given_keys;
+  if(type && soft_out && !fused)
+    k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, type, ctx->soft[0], ctx->soft[1], ctx->soft[2],
+                                                 ctx->soft[3], ctx->soft[4], ctx->soft[5],
+                                                 ctx->adaptive_gravsoft ? P<double>(ctx->f[GHIP_F_HSML]) : nullptr,
+                                                 soft_out);
+  if(fused)
+    k_keys_fused<<<cdiv(n, 256), 256, 0, st>>>(
+      n, type, ctx->soft[0], ctx->soft[1], ctx->soft[2], ctx->soft[3], ctx->soft[4], ctx->soft[5],
+      ctx->adaptive_gravsoft ? P<double>(ctx->f[GHIP_F_HSML]) : nullptr, x, y, z, ctx->corner[0],
+      ctx->corner[1], ctx->corner[2], fac, soft_out, P<unsigned long long>(t.key), P<int>(t.idx),
+      P<unsigned int>(t.phkey));
+  else
+    k_morton_from_pos<<<cdiv(n, 256), 256, 0, st>>>(n, x, y, z, ctx->corner[0], ctx->corner[1],
+                                                    ctx->corner[2], fac,
+                                                    P<unsigned long long>(t.key), P<int>(t.idx));
   if(given_keys && nlocal >= 0 && nlocal < n)
     k_override_keys<<<cdiv(n - nlocal, 256), 256, 0, st>>>(nlocal, n, given_keys,
                                                            P<unsigned long long>(t.key));
@@ -794,12 +1000,9 @@ static int sort_by_key(ghip_ctx *ctx, TreeDev &t, int n, const double *x, const 
     {
       // top 32 key bits first, then the (rare) runs of equal top bits by their full keys
       unsigned int *hi_in = P<unsigned int>(t.phkey), *hi_out = hi_in + n;
-      k_key_hi<<<cdiv(n, 256), 256, 0, st>>>(n, 31, P<unsigned long long>(t.key), hi_in);
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(t.idx),
-                                                P<int>(t.perm), n, 0, 32, st));
-      GCHK(cub_tmp(ctx, tb));
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(t.idx),
-                                                P<int>(t.perm), n, 0, 32, st));
+      if(!fused)
+        k_key_hi<<<cdiv(n, 256), 256, 0, st>>>(n, 31, P<unsigned long long>(t.key), hi_in);
+      GCHK(sort_pairs_u32(ctx, hi_in, hi_out, P<int>(t.idx), P<int>(t.perm), n, 32, st, ctx->cubtmp));
       k_gather_keys<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), P<unsigned long long>(t.key),
                                                   P<unsigned long long>(t.skey));
       k_fix_runs<<<cdiv(n, 256), 256, 0, st>>>(n, 32, P<unsigned long long>(t.skey),
@@ -830,9 +1033,10 @@ static int gas_order_from_gravity_tree(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, t.perm, (size_t) ng * 4));
   GCHK(ghip_ensure(ctx, ctx->dtgt_a, (size_t) n * 4 + 16));
   GCHK(ghip_ensure(ctx, ctx->dtgt_b, (size_t) n * 4 + 16));
-  k_gas_flags<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.perm), P<int>(ctx->dtgt_a));
+  const int wg = ghip_wg(ctx);
+  k_gas_flags<<<cdiv(n, wg), wg, 0, st>>>(n, ng, P<int>(g.perm), P<int>(ctx->dtgt_a));
   GCHK(exclusive_sum(ctx, P<int>(ctx->dtgt_a), P<int>(ctx->dtgt_b), n));
-  k_gas_compact<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.perm),
+  k_gas_compact<<<cdiv(n, wg), wg, 0, st>>>(n, ng, P<int>(g.perm),
                                               P<unsigned long long>(g.skey), P<int>(ctx->dtgt_b),
                                               P<int>(t.perm), P<unsigned long long>(t.skey));
   HIPCHK(hipGetLastError());
@@ -857,11 +1061,11 @@ static int count_nodes(ghip_ctx *ctx, TreeDev &t, int n, bool gas, int cap_nodes
       k_gather_i32<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.perm), src_lvl, P<int>(t.slvl));
       slvl = P<int>(t.slvl);
     }
-  k_prefix_levels<<<cdiv(n, 1024), 1024, 0, st>>>(n, P<unsigned long long>(t.skey), slvl,
-                                                  P<int>(t.cpl), dinfo);
-  k_node_counts<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.cpl), slvl, P<int>(t.cnt),
-                                              ghip_errword(ctx, GHIP_ERRW_TREE));
+  const int wgp = ctx->grav_pending ? 64 : 1024, wg = ghip_wg(ctx);
+  k_prefix_counts<<<cdiv(n, wgp), wgp, 0, st>>>(n, P<unsigned long long>(t.skey), slvl, P<int>(t.cpl),
+                                                P<int>(t.cnt), dinfo, ghip_errword(ctx, GHIP_ERRW_TREE));
   HIPCHK(hipGetLastError());
+  (void) wg;
   GCHK(exclusive_sum(ctx, P<int>(t.cnt), P<int>(t.nb), n));
   k_tree_info<<<1, 1, 0, st>>>(n, P<int>(t.nb), P<int>(t.cnt), dinfo, cap_nodes, wide ? 1 : 0,
                                ctx->build_gen, P<TreeSizes>(t.dsz), t.hsz);
@@ -983,15 +1187,11 @@ static int curve_order(ghip_ctx *ctx, hipStream_t st)
   TreeDev &g = ctx->gt, &t = ctx->st;
   // (multi-GPU: the gravity tree holds imported elements too, and the shard's gas tree -- local gas
   // plus ghosts -- gets its own order from ghip_dd.hip)
-  int n = g.n, ng = ctx->dd.on ? 0 : ctx->ngas;
+  int n = g.n;
   GCHK(ghip_ensure(ctx, g.phorder, (size_t) n * 4));
-  if(ng > 0)
-    GCHK(ghip_ensure(ctx, t.phorder, (size_t) ng * 4));
   if(getenv("GHIP_TARGET_ORDER") && !strcmp(getenv("GHIP_TARGET_ORDER"), "morton"))
     {
       k_iota_tree<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(g.phorder));
-      if(ng > 0)
-        k_iota_tree<<<cdiv(ng, 256), 256, 0, st>>>(ng, P<int>(t.phorder));
       HIPCHK(hipGetLastError());
       return GHIP_OK;
     }
@@ -1007,38 +1207,34 @@ static int curve_order(ghip_ctx *ctx, hipStream_t st)
                                            ctx->corner[2], fac, hi_in, P<int>(g.idx));
   HIPCHK(hipGetLastError());
   // (a 32-bit hipcub sort with begin_bit != 0 mis-sorts on this ROCm: the digits sit at bit 0)
-  size_t tb = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(g.idx),
-                                            P<int>(g.phorder), n, 0, 3 * levels, st));
-  GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(g.idx),
-                                            P<int>(g.phorder), n, 0, 3 * levels, st));
-  if(ng > 0)
-    {
-      // the gas targets in the same order: compaction of the list above (rank[] = dtgt_b)
-      GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
-      int *flag = P<int>(ctx->dflags), *pos = P<int>(ctx->dtgt_a);
-      k_gas_flags_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm), flag);
-      GCHK(exclusive_sum(ctx, flag, pos, n, st));
-      k_gas_compact_ph<<<cdiv(n, 256), 256, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm),
-                                                     P<int>(ctx->dtgt_b), pos, P<int>(t.phorder));
-      HIPCHK(hipGetLastError());
-    }
+  DevBuf &tmp = (st == ctx->stream) ? ctx->cubtmp : ctx->cubtmp2;
+  GCHK(sort_pairs_u32(ctx, hi_in, hi_out, P<int>(g.idx), P<int>(g.phorder), n, 3 * levels, st, tmp));
   return GHIP_OK;
 }
 
-// hsml != nullptr: ADAPTIVE_GRAVSOFT_FORGAS, a gas particle is softened with its Hsml
-// (forcetree.c:705-716, 1851-1856, 2038-2058)
-__global__ void k_soft_of_type(int n, const int *__restrict__ type, double s0, double s1, double s2,
-                               double s3, double s4, double s5, const double *__restrict__ hsml,
-                               double *__restrict__ out)
+// the gas targets in the gravity targets' order: compaction of that list (rank[] = dtgt_b, left by
+// gas_order_from_gravity_tree)
+static int gas_curve_order(ghip_ctx *ctx)
 {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  int t = type[i];
-  out[i] = (t == 0) ? (hsml ? hsml[i] : s0)
-                    : (t == 1) ? s1 : (t == 2) ? s2 : (t == 3) ? s3 : (t == 4) ? s4 : s5;
+  TreeDev &g = ctx->gt, &t = ctx->st;
+  const int n = g.n, ng = ctx->ngas;
+  hipStream_t st = ctx->stream;
+  const int wg = ghip_wg(ctx);
+  GCHK(ghip_ensure(ctx, t.phorder, (size_t) ng * 4));
+  if(getenv("GHIP_TARGET_ORDER") && !strcmp(getenv("GHIP_TARGET_ORDER"), "morton"))
+    {
+      k_iota_tree<<<cdiv(ng, wg), wg, 0, st>>>(ng, P<int>(t.phorder));
+      HIPCHK(hipGetLastError());
+      return GHIP_OK;
+    }
+  GCHK(ghip_ensure(ctx, ctx->dflags, (size_t) n * 4));
+  int *flag = P<int>(ctx->dflags), *pos = P<int>(ctx->dtgt_a);
+  k_gas_flags_ph<<<cdiv(n, wg), wg, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm), flag);
+  GCHK(exclusive_sum(ctx, flag, pos, n, st));
+  k_gas_compact_ph<<<cdiv(n, wg), wg, 0, st>>>(n, ng, P<int>(g.phorder), P<int>(g.perm),
+                                               P<int>(ctx->dtgt_b), pos, P<int>(t.phorder));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
 }
 
 static void tree_reset(TreeDev &t, int n)
@@ -1104,7 +1300,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   if(dd)
     ctx->st.built = false;
   ctx->gas_pending = false;
-  ctx->lists_dirty = true;
+  ctx->lists_dirty = ctx->gas_list_dirty = true;
   ctx->stats.tree_nodes = ctx->stats.gastree_nodes = 0;
   if(nsrc == 0)
     {
@@ -1117,7 +1313,7 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   GCHK(ghip_ensure(ctx, ctx->ssoft, (size_t) nsrc * 8));
   GCHK(ghip_ensure(ctx, ctx->soldacc, (size_t) nsrc * 8));
   double *tmp_soft = P<double>(ctx->soldacc);  // scratch until the first gravity call
-  if(n > 0)
+  if(n > 0 && nimp > 0)   // (without imports the softenings come out of the key kernel, sort_by_key)
     k_soft_of_type<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(ctx->f[GHIP_F_TYPE]), ctx->soft[0],
                                                  ctx->soft[1], ctx->soft[2], ctx->soft[3],
                                                  ctx->soft[4], ctx->soft[5],
@@ -1165,31 +1361,23 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       GCHK(tree_ensure_elements(ctx, G, nsrc, G.last_nnodes + G.last_nnodes / 16 + 256 > G.cap_nodes
                                                 ? G.last_nnodes + G.last_nnodes / 4 + 4096
                                                 : G.cap_nodes));
-      if(use_gas)
-        GCHK(tree_ensure_elements(ctx, S, ng, S.last_nnodes + S.last_nnodes / 16 + 256 > S.cap_nodes
-                                                ? S.last_nnodes + S.last_nnodes / 4 + 4096
-                                                : S.cap_nodes));
     }
   ctx->build_gen++;
   ctx->grav_log.clear();
   ctx->tree_unverified = false;
+  ctx->gas_unverified = false;
+  ctx->gas_async = async;
   bool wide = ctx->sort_wide || (getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1);
   for(;;)
     {
-      HIPCHK(hipMemsetAsync(tree_dinfo(ctx, false), 0, 16, st));
-      GCHK(sort_by_key(ctx, G, nsrc, x, y, z, wide, n, given_keys));
+      GCHK(sort_by_key(ctx, G, nsrc, x, y, z, wide, n, given_keys, false,
+                       nimp == 0 ? P<int>(ctx->f[GHIP_F_TYPE]) : nullptr, tmp_soft));
       GCHK(count_nodes(ctx, G, nsrc, false, async ? G.cap_nodes : 0x7fffffff, wide, src_lvl));
-      if(use_gas)
-        {
-          GCHK(gas_order_from_gravity_tree(ctx));
-          GCHK(count_nodes(ctx, S, ng, true, async ? S.cap_nodes : 0x7fffffff, wide));
-        }
       HIPCHK(hipEventRecord(ctx->ev_sizes, st));
       if(async)
         break;
       HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes));   // the one host round trip of a synchronous build
-      const bool longrun = G.hsz->bad == 2 || (use_gas && S.hsz->bad == 2);
-      if(wide || !longrun)
+      if(wide || G.hsz->bad != 2)
         break;
       wide = true;   // strongly clustered input: long runs of equal top key bits, sort full keys ...
       ctx->sort_wide = true;   // ... from now on
@@ -1199,19 +1387,10 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
       // host copies: the last verified build's, until ghip_tree_verify brings this build's
       G.nnodes = G.last_nnodes;
       G.nelem = nsrc + G.nnodes;
-      if(use_gas)
-        {
-          S.nnodes = S.last_nnodes;
-          S.nelem = ng + S.nnodes;
-        }
       ctx->tree_unverified = true;
     }
   else
-    {
-      GCHK(tree_adopt_sizes(ctx, G, true));
-      if(use_gas)
-        GCHK(tree_adopt_sizes(ctx, S, true));
-    }
+    GCHK(tree_adopt_sizes(ctx, G, true));
 
   GCHK(ghip_ensure(ctx, ctx->sx, (size_t) nsrc * 8));
   GCHK(ghip_ensure(ctx, ctx->sy, (size_t) nsrc * 8));
@@ -1235,10 +1414,10 @@ int ghip_tree_build_impl(ghip_ctx *ctx)
   HIPCHK(hipEventRecord(ctx->evt[1], ctx->stream2));
   HIPCHK(hipStreamWaitEvent(st, ctx->evt[1], 0));
 
-  // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml.  Its order, node
-  // counts and curve order are known; the rest of its build is deferred to the first call that
-  // needs it (ghip_finish_gas_tree), which normally is ghip_density -- enqueued while a gravity
-  // pair is in flight, so that this work runs underneath the walks.
+  // gas tree over host indices [0, ngas): same cells, gas only; aux = Hsml.  Its order is the
+  // gravity tree's with the other types removed.  All of its build is deferred to the first call that
+  // needs it (ghip_finish_gas_tree), which normally is ghip_density -- enqueued while a gravity pair
+  // is in flight, so that this work runs underneath the walks instead of in front of them.
   if(use_gas)
     ctx->gas_pending = true;
   HIPCHK(hipGetLastError());
@@ -1345,7 +1524,7 @@ int ghip_dd_build_gas_tree(ghip_ctx *ctx)
   TreeDev &t = ctx->st;
   tree_reset(t, nsg);
   ctx->gas_pending = false;
-  ctx->lists_dirty = true;
+  ctx->lists_dirty = ctx->gas_list_dirty = true;
   ctx->stats.gastree_nodes = 0;
   if(nsg == 0)
     return GHIP_OK;
@@ -1365,7 +1544,6 @@ int ghip_dd_build_gas_tree(ghip_ctx *ctx)
   bool wide = ctx->sort_wide || (getenv("GHIP_SORT64") && atoi(getenv("GHIP_SORT64")) == 1);
   for(;;)
     {
-      HIPCHK(hipMemsetAsync(tree_dinfo(ctx, true), 0, 8, st));
       GCHK(sort_by_key(ctx, t, nsg, gx, gy, gz, wide, -1, nullptr, true));
       GCHK(count_nodes(ctx, t, nsg, true, 0x7fffffff, wide));
       HIPCHK(ghip_stream_sync(ctx, st));
@@ -1412,12 +1590,7 @@ int ghip_dd_build_gas_tree(ghip_ctx *ctx)
                                              ctx->corner[0], ctx->corner[1], ctx->corner[2], fac,
                                              hi_in, P<int>(t.idx));
   HIPCHK(hipGetLastError());
-  size_t tb = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, hi_in, hi_out, P<int>(t.idx),
-                                            P<int>(t.phorder), nsg, 0, 3 * levels, st));
-  GCHK(cub_tmp(ctx, tb));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubtmp.p, tb, hi_in, hi_out, P<int>(t.idx),
-                                            P<int>(t.phorder), nsg, 0, 3 * levels, st));
+  GCHK(sort_pairs_u32(ctx, hi_in, hi_out, P<int>(t.idx), P<int>(t.phorder), nsg, 3 * levels, st, ctx->cubtmp));
   ctx->stats.gastree_nodes = t.nnodes;
   return GHIP_OK;
 }
@@ -1439,34 +1612,84 @@ int ghip_dd_refresh_ghosts(ghip_ctx *ctx)
   return ghip_gastree_refresh_hmax(ctx);
 }
 
-int ghip_finish_gas_tree(ghip_ctx *ctx)
+// the deferred build of the gas tree: its order out of the gravity tree's, node counts, elements,
+// moments (hmax), SphNode records, gas records, curve order of the gas targets
+static int build_gas_tree(ghip_ctx *ctx, bool async)
 {
-  if(!ctx->gas_pending || ctx->gas_wait_upload)
-    return GHIP_OK;
-  ctx->gas_pending = false;
   const int n = ctx->n, ng = ctx->ngas;
   hipStream_t st = ctx->stream;
+  TreeDev &S = ctx->st;
   const double *x = P<double>(ctx->f[GHIP_F_POS]);
   const double *y = x + n, *z = y + n;
   const double *m = P<double>(ctx->f[GHIP_F_MASS]);
   const double *h = P<double>(ctx->f[GHIP_F_HSML]);
-  GCHK(ghip_ensure(ctx, ctx->st.iperm, (size_t) ng * 4));
+  S.n = ng;
+  if(async)
+    GCHK(tree_ensure_elements(ctx, S, ng, S.last_nnodes + S.last_nnodes / 16 + 256 > S.cap_nodes
+                                            ? S.last_nnodes + S.last_nnodes / 4 + 4096
+                                            : S.cap_nodes));
+  GCHK(gas_order_from_gravity_tree(ctx));
+  GCHK(count_nodes(ctx, S, ng, true, async ? S.cap_nodes : 0x7fffffff, true));
+  HIPCHK(hipEventRecord(ctx->ev_sizes_gas, st));
+  if(async)
+    {
+      S.nnodes = S.last_nnodes;
+      S.nelem = ng + S.nnodes;
+      ctx->gas_unverified = true;
+    }
+  else
+    {
+      HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes_gas));
+      GCHK(tree_adopt_sizes(ctx, S, true));
+      ctx->gas_unverified = false;
+    }
+  GCHK(ghip_ensure(ctx, S.iperm, (size_t) ng * 4));
   GCHK(ghip_ensure(ctx, ctx->stage, (size_t) ng * 5 * sizeof(double)));
   double *s = P<double>(ctx->stage);
-  GCHK(emit_tree(ctx, ctx->st, ng, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng,
-                 s + 3 * (size_t) ng, s + 4 * (size_t) ng, false));
-  ctx->st.built = true;
+  GCHK(emit_tree(ctx, S, ng, x, y, z, m, h, s, s + ng, s + 2 * (size_t) ng, s + 3 * (size_t) ng,
+                 s + 4 * (size_t) ng, false));
+  S.built = true;
   GCHK(ghip_sph_fill_nodes(ctx, false));
   GCHK(ghip_ensure(ctx, ctx->gp, (size_t) ng * 64));
   GCHK(ghip_ensure(ctx, ctx->gq, (size_t) ng * 64));
   const double *vp = P<double>(ctx->f[GHIP_F_VELPRED]);
   k_gather_gas<<<cdiv(ng, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
-    ng, P<int>(ctx->st.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
+    ng, P<int>(S.perm), x, y, z, m, vp, vp + ng, vp + 2 * (size_t) ng, h,
     P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
     P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
     P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
     P<double>(ctx->gq));
   HIPCHK(hipGetLastError());
+  GCHK(gas_curve_order(ctx));
+  ctx->gas_list_dirty = true;
+  ctx->stats.gastree_nodes = S.nnodes;
+  return GHIP_OK;
+}
+
+int ghip_finish_gas_tree(ghip_ctx *ctx)
+{
+  if(!ctx->gas_pending || ctx->gas_wait_upload)
+    return GHIP_OK;
+  ctx->gas_pending = false;
+  return build_gas_tree(ctx, ctx->gas_async && ctx->st.last_n == ctx->ngas && ctx->st.cap_nodes > 0);
+}
+
+// the gas tree's counterpart of ghip_tree_verify: before the h iteration modifies smoothing lengths
+int ghip_gas_verify(ghip_ctx *ctx)
+{
+  if(!ctx->gas_unverified)
+    return GHIP_OK;
+  ctx->gas_unverified = false;
+  HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes_gas));
+  GCHK(tree_adopt_sizes(ctx, ctx->st, false));
+  ctx->stats.gastree_nodes = ctx->st.nnodes;
+  if(ctx->st.hsz->bad != 0)
+    {
+      // nothing has used the tree yet (nelem = 0 on the device): once more, with the host waiting for
+      // the count and the buffers grown to it
+      HIPCHK(ghip_stream_sync(ctx, ctx->stream));
+      return build_gas_tree(ctx, false);
+    }
   return GHIP_OK;
 }
 
@@ -1516,7 +1739,7 @@ static int tree_recover(ghip_ctx *ctx)
     r = ghip_fail(ctx, GHIP_EHIP, "tree recovery: stream synchronisation failed");
   ctx->n_syncs += 3;
   ctx->grav_pending = false;
-  if(ctx->gt.hsz->bad == 2 || (ctx->ngas > 0 && ctx->st.hsz->bad == 2))
+  if(ctx->gt.hsz->bad == 2)
     ctx->sort_wide = true;
   if(r == GHIP_OK)
     r = ghip_tree_build_impl(ctx);
@@ -1537,13 +1760,9 @@ int ghip_tree_verify(ghip_ctx *ctx)
     return GHIP_OK;
   ctx->tree_unverified = false;
   HIPCHK(ghip_event_sync(ctx, ctx->ev_sizes));   // the counting stage only: the walks may still be running
-  const bool use_gas = ctx->ngas > 0 && !ctx->dd.on;
   GCHK(tree_adopt_sizes(ctx, ctx->gt, false));
-  if(use_gas)
-    GCHK(tree_adopt_sizes(ctx, ctx->st, false));
   ctx->stats.tree_nodes = ctx->gt.nnodes;
-  ctx->stats.gastree_nodes = ctx->st.nnodes;
-  if(ctx->gt.hsz->bad != 0 || (use_gas && ctx->st.hsz->bad != 0))
+  if(ctx->gt.hsz->bad != 0)
     return tree_recover(ctx);
   return GHIP_OK;
 }
@@ -1646,17 +1865,23 @@ static int permute_for_shards(ghip_ctx *ctx, DevBuf &list, int nt)
 
 int ghip_build_target_lists(ghip_ctx *ctx)
 {
-  if(!ctx->lists_dirty)
-    return GHIP_OK;
-  if(ctx->nactive >= 0)
+  if(ctx->nactive >= 0 && (ctx->lists_dirty || ctx->gas_list_dirty))
     GCHK(ghip_finish_gas_tree(ctx));   // an active subset is marked through st.iperm
-  GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
-  if(ctx->dd.on && !ctx->st.built)
-    ctx->nt_gas = 0;   // multi-GPU: the gas list is made when the shard's gas tree exists (ghip_dd.hip)
-  else
-    GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
-  GCHK(permute_for_shards(ctx, ctx->tg_grav, ctx->nt_grav));
-  GCHK(permute_for_shards(ctx, ctx->tg_gas, ctx->nt_gas));
-  ctx->lists_dirty = false;
+  if(ctx->lists_dirty)
+    {
+      GCHK(make_list(ctx, ctx->gt, ctx->n, ctx->tg_grav, &ctx->nt_grav));
+      GCHK(permute_for_shards(ctx, ctx->tg_grav, ctx->nt_grav));
+      ctx->lists_dirty = false;
+    }
+  // the gas list follows once the (deferred) gas tree exists: the gravity walks do not need it
+  if(ctx->gas_list_dirty && !ctx->gas_pending)
+    {
+      if(ctx->dd.on && !ctx->st.built)
+        ctx->nt_gas = 0;   // multi-GPU: the gas list is made when the shard's gas tree exists (ghip_dd.hip)
+      else
+        GCHK(make_list(ctx, ctx->st, ctx->ngas, ctx->tg_gas, &ctx->nt_gas));
+      GCHK(permute_for_shards(ctx, ctx->tg_gas, ctx->nt_gas));
+      ctx->gas_list_dirty = false;
+    }
   return GHIP_OK;
 }
