@@ -78,6 +78,12 @@ def build(force=False, verbose=False):
 
 
 def lib_path():
+    # (development: an A/B build of the library, tests/build_variant.sh)
+    alt = os.environ.get("GHIP_LIBGHIP")
+    if alt:
+        if not os.path.exists(alt):
+            raise RuntimeError("GHIP_LIBGHIP=%s does not exist" % alt)
+        return alt
     if not os.path.exists(LIBGHIP):
         raise RuntimeError(
             "libghip.so is missing (%s): run __graft_entry__.build() -- there is no CPU fallback"

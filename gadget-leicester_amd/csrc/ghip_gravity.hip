@@ -260,6 +260,7 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   k.asmthfac = (p->Asmth > 0) ? 0.5 / p->Asmth * (GHIP_NTAB / 3.0) : 0;  // forcetree.c:2378
   k.fac_intp = (p->BoxSize > 0) ? 2 * GHIP_EN / p->BoxSize : 0;
   k.debug_steps = getenv("GHIP_DEBUG_STEPS") ? 1 : 0;
+  k.k1875 = 1.875;
   if(ctx->dd.on)
     {
       // where a walk reports that it had to open an imported pruned node (d_walk_errw)
@@ -537,20 +538,29 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
         pl.started_at = blocks - 1;
     }
   // In a pair the Newtonian walk must leave room for the Ewald walk: at its full 8 wavefronts per
-  // SIMD it owns the whole register file and the two kernels merely follow each other.  8 KB of
-  // (unused) dynamic LDS per one-wavefront workgroup caps it at 20 per CU = 5 per SIMD, which
-  // leaves registers for Ewald wavefronts next to them: 13.0 -> 11.4 ms per step at c2.
+  // SIMD it owns the whole register file and the two kernels merely follow each other.  (Unused)
+  // dynamic LDS per one-wavefront workgroup caps it: 8 KB = 20 per CU = 5 per SIMD (13.0 -> 11.4 ms
+  // per step at c2 when it was introduced); 10 KB = 4 per SIMD since the round-3 instruction diet of
+  // the visit made the Newtonian wavefronts quicker (same build, c2: 8.59 ms with 8 KB -- the Ewald
+  // walk then ends after the Newtonian one and hydro after both -- 8.43 with 10 KB; the LDS
+  // allocation granularity leaves nothing in between).
   static int lds_n = -1;
   if(lds_n < 0)
-    lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 8192;
+    lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 10240;
   // (only when the launch is large enough to fill the chip by itself: a small share of a
   // multi-GPU run leaves room anyway -- measured on c2's shards: 2048 buckets (4 shards) 4.0 -> 3.7 ms
   // with the cap, 1024 buckets (8 shards) 2.38 -> 2.45 ms)
   static int cap_min = -1;
   if(cap_min < 0)
     cap_min = getenv("GHIP_PAIR_CAP_MIN") ? atoi(getenv("GHIP_PAIR_CAP_MIN")) : 1536;
+  // (the same handle on the pair's Ewald walk, off by default: GHIP_PAIR_EWALD_LDS)
+  static int lds_e = -1;
+  if(lds_e < 0)
+    lds_e = getenv("GHIP_PAIR_EWALD_LDS") ? atoi(getenv("GHIP_PAIR_EWALD_LDS")) : 0;
   const size_t dyn_lds =
-    (MODE == GHIP_WALK_NEWTON && stream != ctx->stream && nbuckets >= cap_min) ? (size_t) lds_n : 0;
+    (MODE == GHIP_WALK_NEWTON && stream != ctx->stream && nbuckets >= cap_min)
+      ? (size_t) lds_n
+      : ((MODE == GHIP_WALK_EWALD && stream != ctx->stream && nbuckets >= cap_min) ? (size_t) lds_e : 0);
 #define GHIP_LAUNCH_WALK(PER, UNEQ)                                                              \
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \

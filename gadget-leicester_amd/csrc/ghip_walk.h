@@ -35,6 +35,15 @@
 #ifndef GHIP_WALK_WAVES
 #define GHIP_WALK_WAVES 8   // wavefronts per SIMD the register allocator must leave room for
 #endif
+// instruction diet of the element visit, bit by bit (for A/B builds; all on by default):
+//   1  the distance first, ONE compare "is any lane further than half a box away" in front of the
+//      three per-axis nearest-image compares
+//   2  interaction count: "mass > 0" is a property of the (wave-uniform) record: scalar test, one add
+//   4  unsoftened interaction: the skip index is taken over inside the interaction's execution region
+//   8  the constant 1.5 of the reciprocal-cube step stays in a register pair
+#ifndef GHIP_WALK_OPT
+#define GHIP_WALK_OPT 15
+#endif
 
 
 struct GravK
@@ -47,6 +56,7 @@ struct GravK
   int xcd_remap;       // GHIP_WALK_XCD=1: XCD-contiguous block order (off: measured slower)
   double rcut, rcut2, asmthfac;  // shortrange
   double fac_intp;     // ewald: 2*EN/BoxSize
+  double k1875;        // 1.875 (a kernel argument lives in scalar registers: see d_mass_over_r3)
 };
 
 // multi-GPU: the device error word (pinned host memory) a wavefront sets when a lane has to open an
@@ -54,7 +64,9 @@ struct GravK
 // (never taken) path, so the walk loop carries no register for it.
 __device__ int *d_walk_errw = nullptr;
 
-// hot half of an element (64 B):  x, y, z, mass | (mass*len)*len, len*len | skip, pidx | aux
+// hot half of an element (64 B):  x, y, z, mass | (mass*len)*len, len*len | skip, flags | aux
+//   flags (the word called pidx below): sign bit = node, bit 0 = "mass > 0" (the interaction counts,
+//   forcetree.c:2214) -- both are properties of the record, so the walk tests them on the scalar unit
 //   node: centre of mass, opening-criterion operands in the reference's operation order
 //   (forcetree.c:2085), aux = max softening below (negative: mixed softenings)
 //   particle: position, 0, 0, aux = its softening
@@ -176,12 +188,15 @@ __device__ __forceinline__ double d_rsqrt(double x)
 // m / r^3 for the unsoftened interaction: y0 = v_rsq_f64(x), e = 1 - x*y0^2,
 // m*y^3 = m*y0^3 * (1 + 3e/2 + 15e^2/8 + O(e^3))   -- the same third-order step as d_rsqrt, cubed (7
 // operations where d_rsqrt and three multiplications take 8)
-__device__ __forceinline__ double d_mass_over_r3(double mass, double x)
+__device__ __forceinline__ double d_mass_over_r3(double mass, double x, double k15 = 1.5,
+                                                 double k1875 = 1.875)
 {
   double y = __builtin_amdgcn_rsq(x);
   double y2 = y * y;
   double e = fma(-x, y2, 1.0);
-  double p = fma(1.875, e, 1.5);
+  // (neither constant is an inline constant of the instruction set.  Kept by the caller in a vector
+  // and a scalar register pair they cost nothing per visit; as literals they cost two moves.)
+  double p = fma(k1875, e, k15);
   double c = (mass * y) * y2;
   return fma(c * e, p, c);
 }
@@ -306,6 +321,7 @@ struct WalkLane
 {
   double pos_x, pos_y, pos_z, h_i, aold;
   double h2;   // h_i^2
+  double k15;  // 1.5, opaque to the compiler (see GHIP_WALK_OPT bit 8)
   double acc_x, acc_y, acc_z;
   int nint;
 };
@@ -337,6 +353,14 @@ typedef unsigned long long lmask;
 #define D_BAL(cond) __builtin_amdgcn_ballot_w64(cond)
 #define D_LANE(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 
+// my_skip = max(my_skip, skip) for the lanes of the current execution mask, in place: as one
+// instruction on one register (written as a select or a plain max the compiler keeps two copies of
+// the index alive and moves them twice per visit)
+__device__ __forceinline__ void d_skip_to(int &my_skip, int skip)
+{
+  asm volatile("v_max_i32 %0, %1, %0" : "+v"(my_skip) : "s"(skip));
+}
+
 // One element of the list for all 64 lanes.  H = hot record (already in SGPRs).  OWNED = false
 // replays only the opening decision (ancestor of a segment).  Returns the next element index
 // (wave-uniform).  All 64 lanes are active here (lanes without a target carry my_skip = INT_MAX).
@@ -355,7 +379,34 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   int next;
 
   double dx = ex - W.pos_x, dy = ey - W.pos_y, dz = ez - W.pos_z;
-  if(MODE == GHIP_WALK_EWALD || PERIODIC)
+  double r2;
+  if((GHIP_WALK_OPT & 1) && (MODE == GHIP_WALK_EWALD || PERIODIC))
+    {
+      // No lane needs a nearest-image shift unless its distance reaches half a box: |d_k| > boxhalf
+      // implies r2 >= boxhalf^2 (the sum only grows and rounding is monotone).  One compare in the
+      // common case; otherwise the per-axis shifts under their masks and the distance once more.
+      r2 = dx * dx + dy * dy + dz * dz;
+      if(D_BAL(r2 >= p.boxhalf * p.boxhalf) != 0)
+        {
+          if(D_LANE(D_BAL(fabs(dx) > p.boxhalf)))
+            {
+              dx -= copysign(p.boxsize, dx);
+              asm volatile("" : "+v"(dx));
+            }
+          if(D_LANE(D_BAL(fabs(dy) > p.boxhalf)))
+            {
+              dy -= copysign(p.boxsize, dy);
+              asm volatile("" : "+v"(dy));
+            }
+          if(D_LANE(D_BAL(fabs(dz) > p.boxhalf)))
+            {
+              dz -= copysign(p.boxsize, dz);
+              asm volatile("" : "+v"(dz));
+            }
+          r2 = dx * dx + dy * dy + dz * dz;
+        }
+    }
+  else if(MODE == GHIP_WALK_EWALD || PERIODIC)
     {
       // nearest image (forcetree.c:49): three compares into lane masks, ONE scalar test for "no lane
       // on any axis" -- the common case -- and only otherwise the per-axis shifts under their masks
@@ -379,8 +430,10 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
               asm volatile("" : "+v"(dz));
             }
         }
+      r2 = dx * dx + dy * dy + dz * dz;
     }
-  const double r2 = dx * dx + dy * dy + dz * dz;
+  else
+    r2 = dx * dx + dy * dy + dz * dz;
   double h = W.h_i, h2 = W.h2;
   lmask interact;
 
@@ -493,8 +546,11 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
             }
         }
       interact = act & ~drop & ~open;
-      if(D_LANE(interact | drop))
-        my_skip = skip;
+      // (the unsoftened Newtonian interaction below takes the skip index over inside its own execution
+      // region; a lane inside its softening length goes through the general block and is handled here)
+      if(!((GHIP_WALK_OPT & 4) && OWNED && MODE == GHIP_WALK_NEWTON) || (interact & D_BAL(r2 < h2)) != 0)
+        if(D_LANE(interact | drop))
+          d_skip_to(my_skip, skip);   // (= skip: my_skip <= e < skip for these lanes)
       next = skip;
       if(open != 0)
         {
@@ -519,13 +575,26 @@ __device__ __forceinline__ int d_walk_element(int e, const v16i &H,
   // of the softened kernel (forcetree.c:2143-2171)
   if(OWNED && MODE == GHIP_WALK_NEWTON && (interact & D_BAL(r2 < h2)) == 0)
     {
+      // mass > 0 as a scalar test on the record's words (a mass is never negative): the high word
+      // positive, or a denormal
+      // "mass > 0": bit 0 of the record's flag word (k_fill_elems)
+      const int counted = pidx & 1;
+      // the skip index, taken over by the interacting lanes: of a node > e >= their my_skip; of a
+      // particle e + 1, which changes nothing (the next element is e + 1 or beyond)
+      const int sk = skip;
       if(D_LANE(interact))
         {
-          const double fac = d_mass_over_r3(mass, r2);
+          const double fac = (GHIP_WALK_OPT & 8) ? d_mass_over_r3(mass, r2, W.k15, p.k1875)
+                                                 : d_mass_over_r3(mass, r2);
           W.acc_x += dx * fac;
           W.acc_y += dy * fac;
           W.acc_z += dz * fac;
-          W.nint += (mass > 0) ? 1 : 0;
+          if(GHIP_WALK_OPT & 2)
+            W.nint += counted;
+          else
+            W.nint += (mass > 0) ? 1 : 0;
+          if(GHIP_WALK_OPT & 4)
+            d_skip_to(my_skip, sk);
         }
       return next;
     }
@@ -778,6 +847,8 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
     }
   W.acc_x = W.acc_y = W.acc_z = 0;
   W.nint = 0;
+  W.k15 = 1.5;
+  asm volatile("" : "+v"(W.k15));   // (not rematerialised inside the loop: two moves per visit otherwise)
   unsigned int steps = 0;
 
   // two copies of the traversal, one per opening criterion (a uniform choice: no divergence)
@@ -994,7 +1065,7 @@ __global__ void k_fill_elems(const TreeSizes *__restrict__ ts, const double4 *__
       q.len06 = 0.60 * c.w;
     }
   h.skip = k.x;
-  h.pidx = k.y;
+  h.pidx = (LK_IS_PARTICLE(k) ? 0 : (int) 0x80000000) | (v.w > 0 ? 1 : 0);   // flags: node, mass > 0
   h.aux = aux[e];
   q.spare[0] = q.spare[1] = q.spare[2] = 0.0;
   hot[e] = h;
