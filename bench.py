@@ -190,6 +190,15 @@ def main():
 
         rccl_error = None
         if transport == "rccl":
+            # ncclCommInitRank is collective: nobody may enter it unless every rank has a librccl to
+            # enter it with -- agreed over gloo BEFORE the connect attempt
+            have = torch.tensor([1.0 if B.dd_rccl_library() else 0.0], dtype=torch.float64)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            if float(have.item()) < 0.5:
+                transport = "host"
+                rccl_error = "librccl could not be loaded on every rank"
+                sys.stderr.write("bench: %s: exchanges staged through the host\n" % rccl_error)
+        if transport == "rccl":
             # every rank must end up on the same transport: agree after the connect attempt
             try:
                 dom = S.DomainRank(fp, rank, world, bcast, transport="rccl")
@@ -378,6 +387,8 @@ def main():
                                     "grav_wave_steps": work["grav_wave_steps"] / K},
         }
         if dom is not None:
+            out["transport"] = transport     # "rccl": RCCL from C (ghip_dd_run); "host": staged through gloo
+            out["rccl_library"] = B.dd_rccl_library() if transport == "rccl" else None
             out["exchange_per_step_rank0"] = {
                 "particles_migrated": migrated / K,
                 "bytes_sent_migration": dd_bytes[0] / K,

@@ -206,20 +206,26 @@ extern "C" int ghip_dd_exchange(ghip_ctx *ctx)
   HIPCHK(ghip_stream_sync(ctx, st));
   recv_layout(x, me, P_, cnt.data());
   GCHK(ghip_ensure(ctx, *x.recv, (size_t) (x.rtotal > 0 ? x.rtotal : 1) * x.bytes));
+  // (a failing send or receive must not leave the group open: the group is always closed, and the
+  // first error is reported afterwards)
   NCHK(g_rccl.GroupStart());
-  for(int peer = 0; peer < P_; peer++)
+  ncclResult_t gr = ncclSuccess;
+  for(int peer = 0; peer < P_ && gr == ncclSuccess; peer++)
     {
       if(peer == me)
         continue;
       if(x.scount[peer] > 0)
-        NCHK(g_rccl.Send(reinterpret_cast<const char *>(x.send) + (size_t) x.soff[peer] * x.bytes,
-                         (size_t) x.scount[peer] * x.bytes, ncclChar, peer, comm, st));
-      if(x.rcount[peer] > 0)
-        NCHK(g_rccl.Recv(reinterpret_cast<char *>(x.recv->p) + (size_t) x.roff[peer] * x.bytes,
-                         (size_t) x.rcount[peer] * x.bytes, ncclChar, peer, comm, st));
+        gr = g_rccl.Send(reinterpret_cast<const char *>(x.send) + (size_t) x.soff[peer] * x.bytes,
+                         (size_t) x.scount[peer] * x.bytes, ncclChar, peer, comm, st);
+      if(gr == ncclSuccess && x.rcount[peer] > 0)
+        gr = g_rccl.Recv(reinterpret_cast<char *>(x.recv->p) + (size_t) x.roff[peer] * x.bytes,
+                         (size_t) x.rcount[peer] * x.bytes, ncclChar, peer, comm, st);
       D.bytes_sent[D.op] += (long long) x.scount[peer] * (long long) x.bytes;
     }
-  NCHK(g_rccl.GroupEnd());
+  const ncclResult_t ge = g_rccl.GroupEnd();
+  if(gr != ncclSuccess)
+    return ghip_fail(ctx, GHIP_ECOMM, "ncclSend / ncclRecv inside the group -> %s", g_rccl.GetErrorString(gr));
+  NCHK(ge);
   if(x.scount[me] > 0)   // (a rank never sends to itself in this path; kept for completeness)
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(x.recv->p) + (size_t) x.roff[me] * x.bytes,
                           reinterpret_cast<const char *>(x.send) + (size_t) x.soff[me] * x.bytes,

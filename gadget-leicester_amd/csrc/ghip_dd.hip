@@ -1070,8 +1070,14 @@ static int density_step(ghip_ctx *ctx)
     {
       // groups of the gas targets (bounding box, padded search radius) from the curve order of the
       // gravity tree: positions in tree order, smoothing lengths through perm
+      // (a density() that no gravity_tree() precedes -- init.c:791 -- orders the shard's own
+      // particles itself: the tree of the local particles, nothing imported)
       if(!ctx->gt.built)
-        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd density: the gravity tree of this step is missing");
+        {
+          GCHK(ghip_join_pair(ctx));
+          D.gt_nimp = 0;
+          GCHK(ghip_tree_build_impl(ctx));
+        }
       GCHK(ghip_build_target_lists(ctx));
       const int nt = ctx->nt_grav;
       int ngt = 0;

@@ -20,6 +20,8 @@
 #include <string.h>
 #include <time.h>
 
+#define GHIP_DD_MAXRANKS_HOST 64   /* GHIP_MAXRANKS of the device library */
+
 /* ---- globals (allvars.c) ---- */
 struct particle_data *P = NULL;
 struct sph_particle_data *SphP = NULL;
@@ -46,8 +48,60 @@ int ThisTask = 0, NTask = 1;
 double CPU_Step_Treewalk = 0, CPU_Step_Treebuild = 0, CPU_Step_Density = 0, CPU_Step_Hydro = 0,
   CPU_Step_Hmaxupdate = 0;
 
+struct topnode_data *TopNodes = NULL;
+int NTopnodes = 0, NTopleaves = 0;
+int *DomainStartList = NULL, *DomainEndList = NULL;
+int N_gas_swallowed = 0, N_BH_swallowed = 0, N_dust_swallowed = 0;
+
 static ghip_ctx *Ctx = NULL;
 static struct gadget_force_config Cfg;
+
+/* ---- the particle records: this header's structs, or the host's own through offsets tables ---- */
+static ghip_layout Lay;                      /* byte offsets in use */
+static struct gadget_force_bh_layout BhLay;  /* ... of the members the sink passes touch (-1: absent) */
+static char *RecP = NULL, *RecS = NULL;      /* bound records (gadget_force_bind_records), else P / SphP */
+
+/* (the offsets of this header's own structs from the moment the library is loaded: some entry points
+ * -- domain_findExtent, density_isactive -- are legitimately called before gadget_force_init) */
+__attribute__((constructor)) static void lay_defaults(void)
+{
+  gadget_force_layout(&Lay);
+  memset(&BhLay, 0xff, sizeof(BhLay));
+  BhLay.p_id = (int) offsetof(struct particle_data, ID);
+  BhLay.s_injected_bh_energy = (int) offsetof(struct sph_particle_data, i);
+}
+
+static inline char *prec(int i)
+{
+  return (RecP ? RecP : (char *) P) + (size_t) i * (size_t) Lay.p_stride;
+}
+static inline char *srec(int i)
+{
+  return (RecP ? RecS : (char *) SphP) + (size_t) i * (size_t) Lay.s_stride;
+}
+#define PF64(i, off) ((double *) (prec(i) + (off)))
+#define SF64(i, off) ((double *) (srec(i) + (off)))
+static inline int p_type(int i) { return (int) *(short *) (prec(i) + Lay.p_type); }
+static inline int p_timebin(int i) { return (int) *(short *) (prec(i) + Lay.p_timebin); }
+static inline double *ppp_hsml(int i)   /* the PPP macro, allvars.h:266-270 */
+{
+  return Lay.p_hsml >= 0 ? PF64(i, Lay.p_hsml) : SF64(i, Lay.s_hsml);
+}
+static inline double *ppp_numngb(int i)
+{
+  return Lay.p_numngb >= 0 ? PF64(i, Lay.p_numngb) : SF64(i, Lay.s_numngb);
+}
+static void *records_p(void) { return RecP ? (void *) RecP : (void *) P; }
+static void *records_s(void) { return RecP ? (void *) RecS : (void *) SphP; }
+
+/* ---- more than one rank ---- */
+static void gravity_tree_ranks(void);
+static void density_ranks(void);
+static void hydro_force_ranks(void);
+static int (*AllgatherFn)(void *, const void *, size_t, void *) = NULL;
+static void *AllgatherUser = NULL;
+static int DdReady = 0;          /* ghip_dd_init done for (ThisTask, NTask) */
+static int RcclConnected = 0;
 static void (*EndrunHandler)(int) = NULL;
 static int DeviceFresh = 0;      /* device copy of P/SphP matches the host arrays */
 static int TreeOnDevice = 0;
@@ -134,7 +188,33 @@ int gadget_force_init(const struct gadget_force_config *cfg)
     }
   DeviceFresh = 0;
   TreeOnDevice = 0;
+  DdReady = 0;
+  RcclConnected = 0;
+  if(!RecP)
+    lay_defaults();
   return GHIP_OK;
+}
+
+void gadget_force_bind_records(void *host_P, void *host_SphP, const ghip_layout *lay,
+                               const struct gadget_force_bh_layout *bh)
+{
+  if(host_P && lay)
+    {
+      RecP = (char *) host_P;
+      RecS = (char *) host_SphP;
+      Lay = *lay;
+      if(bh)
+        BhLay = *bh;
+      else
+        memset(&BhLay, 0xff, sizeof(BhLay));
+    }
+  else
+    {
+      RecP = RecS = NULL;
+      lay_defaults();
+    }
+  DeviceFresh = 0;
+  TreeOnDevice = 0;
 }
 
 void gadget_force_finalize(void)
@@ -342,13 +422,32 @@ void domain_findExtent(void)
 {
   double xmin[3] = { 1e300, 1e300, 1e300 }, xmax[3] = { -1e300, -1e300, -1e300 };
   for(int i = 0; i < NumPart; i++)
-    for(int j = 0; j < 3; j++)
-      {
-        if(xmin[j] > P[i].Pos[j])
-          xmin[j] = P[i].Pos[j];
-        if(xmax[j] < P[i].Pos[j])
-          xmax[j] = P[i].Pos[j];
-      }
+    {
+      const double *pos = PF64(i, Lay.p_pos);
+      for(int j = 0; j < 3; j++)
+        {
+          if(xmin[j] > pos[j])
+            xmin[j] = pos[j];
+          if(xmax[j] < pos[j])
+            xmax[j] = pos[j];
+        }
+    }
+  /* domain.c:1996-1997: more than one rank, the extent of all of them (through the host's all-gather) */
+  if(NTask > 1 && AllgatherFn)
+    {
+      double mine[6] = { xmin[0], xmin[1], xmin[2], xmax[0], xmax[1], xmax[2] };
+      double *all = (double *) malloc((size_t) NTask * sizeof(mine));
+      if(all && AllgatherFn(AllgatherUser, mine, sizeof(mine), all) == 0)
+        for(int r = 0; r < NTask; r++)
+          for(int j = 0; j < 3; j++)
+            {
+              if(all[6 * r + j] < xmin[j])
+                xmin[j] = all[6 * r + j];
+              if(all[6 * r + 3 + j] > xmax[j])
+                xmax[j] = all[6 * r + 3 + j];
+            }
+      free(all);
+    }
   double len = 0;
   for(int j = 0; j < 3; j++)
     if(xmax[j] - xmin[j] > len)
@@ -423,17 +522,15 @@ static int need_ctx(const char *who)
  * are in flight (upload_gas_if_pending) */
 static int upload_particles(int split)
 {
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  if(split && N_gas > 0 && lay.p_hsml < 0)
+  if(split && N_gas > 0 && Lay.p_hsml < 0)
     {
-      if(chk(ghip_upload_aos_particles(Ctx, P, &lay, NumPart, N_gas), "ghip_upload_aos_particles"))
+      if(chk(ghip_upload_aos_particles(Ctx, records_p(), &Lay, NumPart, N_gas), "ghip_upload_aos_particles"))
         return -1;
       GasPending = 1;
     }
   else
     {
-      if(chk(ghip_upload_aos(Ctx, P, SphP, &lay, NumPart, N_gas), "ghip_upload_aos"))
+      if(chk(ghip_upload_aos(Ctx, records_p(), records_s(), &Lay, NumPart, N_gas), "ghip_upload_aos"))
         return -1;
       GasPending = 0;
     }
@@ -447,9 +544,7 @@ static int upload_gas_if_pending(void)
   if(!GasPending)
     return 0;
   GasPending = 0;
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  return chk(ghip_upload_aos_gas(Ctx, SphP, &lay), "ghip_upload_aos_gas") ? -1 : 0;
+  return chk(ghip_upload_aos_gas(Ctx, records_s(), &Lay), "ghip_upload_aos_gas") ? -1 : 0;
 }
 
 /* the active list as the reference threads it (run.c:300-320) */
@@ -458,7 +553,7 @@ static int collect_active(int gas_only)
   int n = 0;
   for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
     {
-      if(gas_only && !(i < N_gas && P[i].Type == 0))
+      if(gas_only && !(i < N_gas && p_type(i) == 0))
         continue;
       if(n >= ActiveCap)
         {
@@ -643,9 +738,7 @@ static int gravity_complete(int download)
       return -1;
   if(download)
     {
-      ghip_layout lay;
-      gadget_force_layout(&lay);
-      if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 1, 0, 0), "ghip_download_aos"))
+      if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 1, 0, 0), "ghip_download_aos"))
         return -1;
     }
   All.TotNumOfForces += GravPendingActive;
@@ -667,6 +760,11 @@ void gravity_tree(void)
 {
   if(need_ctx("gravity_tree"))
     return;
+  if(NTask > 1)
+    {
+      gravity_tree_ranks();
+      return;
+    }
   double t0 = wallclock();
   if(GravPending && gravity_complete(1))   /* accel.c:63-64: the second pass of step 0 needs OldAcc */
     return;
@@ -720,36 +818,95 @@ void gravity_tree(void)
 /* density.c:1030-1052: gas always; sinks under BLACK_HOLES, dust grains under DUST */
 int density_isactive(int n)
 {
-  if(P[n].TimeBin < 0)
+  if(p_timebin(n) < 0)
     return 0;
-  if(Cfg.black_holes && P[n].Type == 5)
+  if(Cfg.black_holes && p_type(n) == 5)
     return 1;
-  if(Cfg.dust && P[n].Type == 2)
+  if(Cfg.dust && p_type(n) == 2)
     return 1;
-  if(P[n].Type == 0)
+  if(p_type(n) == 0)
     return 1;
   return 0;
 }
 
-/* The device density pass evaluates gas targets.  In a BLACK_HOLES / DUST build the reference also
- * iterates the smoothing length of active Type-5 / Type-2 particles against the gas tree
- * (density.c:125, 176, 393 loop over density_isactive) and blackhole.c / the dust loops then read
- * PPP[].Hsml of those particles: rather than leave them stale, refuse loudly. */
-static int refuse_non_gas_density_targets(const char *who)
+/* density() for the active Type-5 (BLACK_HOLES) and Type-2 (DUST) targets -- density.c:125, 176, 393
+ * loop over density_isactive(): the h iteration against the gas tree for DesNumNgb *
+ * BlackHoleNgbFactor (sinks, density.c:549-550) or DesNumNgb (dust grains, :555-556) neighbours
+ * without the Newton step (:613, 629), and the kernel-weighted density, entropy and gas velocity
+ * around the target (:358-377, 522-545).  Their smoothing lengths live in P[] (PPP == P in such a
+ * build, allvars.h:266-270): with the minimal records of this header there is nowhere to put them,
+ * and the call is refused loudly rather than leaving PPP[].Hsml stale. */
+static int density_of_sinks(const ghip_dens_params *d)
 {
   if(!Cfg.black_holes && !Cfg.dust)
     return 0;
-  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
-    if(P[i].Type != 0 && density_isactive(i))
-      {
-        snprintf(ErrBuf, sizeof(ErrBuf),
-                 "%s: active particle %d of type %d is a density target in this build "
-                 "(BLACK_HOLES / DUST); the device density pass handles gas targets only",
-                 who, i, (int) P[i].Type);
-        fprintf(stderr, "gadget_force: %s\n", ErrBuf);
-        endrun(90007);
+  for(int pass = 0; pass < 2; pass++)
+    {
+      const int type = pass == 0 ? 5 : 2;
+      if((type == 5 && !Cfg.black_holes) || (type == 2 && !Cfg.dust))
+        continue;
+      int n = 0;
+      for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+        if(p_type(i) == type && density_isactive(i))
+          n++;
+      if(n == 0)
+        continue;
+      if(Lay.p_hsml < 0)
+        {
+          snprintf(ErrBuf, sizeof(ErrBuf),
+                   "density: %d active particles of type %d are density targets in this build "
+                   "(BLACK_HOLES / DUST), but the bound records keep Hsml in SphP[]: bind the host's "
+                   "records with gadget_force_bind_records()", n, type);
+          fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+          endrun(90007);
+          return -1;
+        }
+      int *idx = (int *) malloc((size_t) n * sizeof(int));
+      double *buf = (double *) malloc((size_t) n * 7 * sizeof(double));
+      if(!idx || !buf)
+        {
+          free(idx);
+          free(buf);
+          endrun(90003);
+          return -1;
+        }
+      double *hs = buf, *nn = buf + n, *rho = buf + 2 * (size_t) n, *ent = buf + 3 * (size_t) n,
+             *vel = buf + 4 * (size_t) n;
+      int k = 0;
+      for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+        if(p_type(i) == type && density_isactive(i))
+          {
+            idx[k] = i;
+            hs[k] = *ppp_hsml(i);
+            k++;
+          }
+      int iter = 0;
+      int rc = ghip_sink_density(Ctx, d, type == 5 ? All.BlackHoleNgbFactor : 1.0, n, idx, hs, nn, rho,
+                                 ent, vel, &iter);
+      if(rc == GHIP_OK)
+        {
+          const int o_rho = type == 5 ? BhLay.p_bh_density : BhLay.p_dust_density;
+          const int o_ent = type == 5 ? BhLay.p_bh_entropy : BhLay.p_dust_entropy;
+          const int o_vel = type == 5 ? BhLay.p_bh_gasvel : BhLay.p_dust_gasvel;
+          for(k = 0; k < n; k++)
+            {
+              const int i = idx[k];
+              *ppp_hsml(i) = hs[k];
+              *ppp_numngb(i) = nn[k];
+              if(o_rho >= 0)
+                *PF64(i, o_rho) = rho[k];
+              if(o_ent >= 0)
+                *PF64(i, o_ent) = ent[k];
+              if(o_vel >= 0)
+                for(int c = 0; c < 3; c++)
+                  PF64(i, o_vel)[c] = vel[3 * (size_t) k + c];
+            }
+        }
+      free(idx);
+      free(buf);
+      if(chk(rc, "ghip_sink_density"))
         return -1;
-      }
+    }
   return 0;
 }
 
@@ -764,13 +921,16 @@ void density(void)
 {
   if(need_ctx("density"))
     return;
+  if(NTask > 1)
+    {
+      density_ranks();
+      return;
+    }
   double t0 = wallclock();
   /* directly after gravity_tree() (accel.c:61-84) the device copy is current; a stand-alone
    * call (init.c:791) re-reads P/SphP */
   if(Phase != 1)
     DeviceFresh = 0;
-  if(refuse_non_gas_density_targets("density"))
-    return;
   if(ensure_tree())
     return;
   int nact = collect_active(1);
@@ -789,9 +949,9 @@ void density(void)
   fill_dens_params(&d);
   if(chk(ghip_density(Ctx, &d), "ghip_density"))
     return;
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, 0, 1, 0), "ghip_download_aos"))
+  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos"))
+    return;
+  if(density_of_sinks(&d))
     return;
   Phase = 2;
   CPU_Step_Density += wallclock() - t0;
@@ -807,7 +967,7 @@ void force_update_hmax(void)
     return;
   /* the reference refreshes Extnodes[].hmax / divVmax in place (forcetree.c:1661-1786): a host that
    * holds the exported tree gets it again with the new smoothing lengths and divergences */
-  if(TreeOnDevice)
+  if(TreeOnDevice && NTask == 1)
     export_tree_to_host();
   CPU_Step_Hmaxupdate += wallclock() - t0;
 }
@@ -817,6 +977,11 @@ void hydro_force(void)
 {
   if(need_ctx("hydro_force"))
     return;
+  if(NTask > 1)
+    {
+      hydro_force_ranks();
+      return;
+    }
   double t0 = wallclock();
   if(Phase != 2)
     DeviceFresh = 0;
@@ -841,9 +1006,7 @@ void hydro_force(void)
   const int with_gravity = GravPending;
   if(with_gravity && gravity_complete(0))
     return;
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  if(chk(ghip_download_aos(Ctx, P, SphP, &lay, with_gravity, 0, 1), "ghip_download_aos"))
+  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, with_gravity, 0, 1), "ghip_download_aos"))
     return;
   Phase = 0;
   CPU_Step_Hydro += wallclock() - t0;
@@ -923,7 +1086,7 @@ static void rebuild_timebin_lists(void)
     }
   for(int i = 0; i < NumPart; i++)
     {
-      int bin = P[i].TimeBin;
+      int bin = p_timebin(i);
       if(NextInTimeBin && PrevInTimeBin)
         {
           if(TimeBinCount[bin] > 0)
@@ -940,7 +1103,7 @@ static void rebuild_timebin_lists(void)
             }
         }
       TimeBinCount[bin]++;
-      if(P[i].Type == 0)
+      if(p_type(i) == 0)
         TimeBinCountSph[bin]++;
     }
 }
@@ -1014,9 +1177,7 @@ void advance_and_find_timesteps(void)
     }
   if(chk(rc, "ghip_advance_timesteps"))
     return;
-  ghip_layout lay;
-  gadget_force_layout(&lay);
-  if(chk(ghip_download_aos_kick(Ctx, P, SphP, &lay), "ghip_download_aos_kick"))
+  if(chk(ghip_download_aos_kick(Ctx, records_p(), records_s(), &Lay), "ghip_download_aos_kick"))
     return;
   rebuild_timebin_lists();
 }
@@ -1057,8 +1218,8 @@ static int treeevaluate_one(int target, int mode, int *nexport, int walk)
              chk(ghip_get_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_get_field"))
             return -1;
           for(int k = 0; k < 3; k++)
-            acc3[3 * (size_t) target + k] = P[target].g.dGravAccel[k];
-          cost[target] = (int) P[target].GravCost;
+            acc3[3 * (size_t) target + k] = PF64(target, Lay.p_gravaccel)[k];
+          cost[target] = (int) *(float *) (prec(target) + Lay.p_gravcost);
           if(chk(ghip_set_field(Ctx, GHIP_F_GRAVACCEL, acc3), "ghip_set_field") ||
              chk(ghip_set_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_set_field"))
             return -1;
@@ -1071,10 +1232,10 @@ static int treeevaluate_one(int target, int mode, int *nexport, int walk)
          chk(ghip_get_field(Ctx, GHIP_F_GRAVCOST, cost), "ghip_get_field"))
         return -1;
       /* forcetree.c:2277-2293 */
-      int before = (int) P[target].GravCost;
+      int before = (int) *(float *) (prec(target) + Lay.p_gravcost);
       for(int k = 0; k < 3; k++)
-        P[target].g.dGravAccel[k] = acc3[3 * (size_t) target + k];
-      P[target].GravCost = (float) cost[target];
+        PF64(target, Lay.p_gravaccel)[k] = acc3[3 * (size_t) target + k];
+      *(float *) (prec(target) + Lay.p_gravcost) = (float) cost[target];
       return (walk == GHIP_WALK_EWALD) ? cost[target] - before : cost[target];
     }
   /* mode 1: an imported target, GravDataGet[target] -> GravDataResult[target]
@@ -1086,7 +1247,7 @@ static int treeevaluate_one(int target, int mode, int *nexport, int walk)
     }
   double pos[3] = { GravDataGet[target].Pos[0], GravDataGet[target].Pos[1],
     GravDataGet[target].Pos[2] };
-  int type = Cfg.unequal_softenings ? GravDataGet[target].Type : P[0].Type; /* forcetree.c:1868-1872 */
+  int type = Cfg.unequal_softenings ? GravDataGet[target].Type : p_type(0); /* forcetree.c:1868-1872 */
   double oldacc = GravDataGet[target].OldAcc, acc[3];
   int nint = 0;
   if(chk(ghip_gravity_ext(Ctx, &g, walk, 1, pos, &type, &oldacc, acc, &nint), "ghip_gravity_ext"))
@@ -1135,15 +1296,15 @@ int density_evaluate(int target, int mode, int *nexport, int *nsend_local)
   ghip_dens_params d;
   fill_dens_params(&d);
   double out7[7];
-  if(chk(ghip_density_evaluate(Ctx, &d, target, PPP[target].Hsml, out7), "ghip_density_evaluate"))
+  if(chk(ghip_density_evaluate(Ctx, &d, target, *ppp_hsml(target), out7), "ghip_density_evaluate"))
     return -1;
-  SphP[target].d.dDensity = out7[0];
-  PPP[target].n.dNumNgb = out7[1];
-  SphP[target].h.dDhsmlDensityFactor = out7[2];
-  SphP[target].v.dDivVel = out7[3];
-  SphP[target].r.dRot[0] = out7[4];
-  SphP[target].r.dRot[1] = out7[5];
-  SphP[target].r.dRot[2] = out7[6];
+  *SF64(target, Lay.s_density) = out7[0];
+  *ppp_numngb(target) = out7[1];
+  *SF64(target, Lay.s_dhsmlfac) = out7[2];
+  *SF64(target, Lay.s_divvel) = out7[3];
+  SF64(target, Lay.s_curlvel)[0] = out7[4];   /* r.dRot[3] shares the union with CurlVel */
+  SF64(target, Lay.s_curlvel)[1] = out7[5];
+  SF64(target, Lay.s_curlvel)[2] = out7[6];
   return 0;
 }
 
@@ -1177,13 +1338,13 @@ int hydro_evaluate(int target, int mode, int *nexport, int *nsend_local)
   if(chk(ghip_get_field(Ctx, GHIP_F_HYDROACCEL, buf), "ghip_get_field"))
     return -1;
   for(int k = 0; k < 3; k++)
-    SphP[target].a.dHydroAccel[k] = buf[3 * (size_t) target + k];
+    SF64(target, Lay.s_hydroaccel)[k] = buf[3 * (size_t) target + k];
   if(chk(ghip_get_field(Ctx, GHIP_F_DTENTROPY, buf), "ghip_get_field"))
     return -1;
-  SphP[target].e.dDtEntropy = buf[target];
+  *SF64(target, Lay.s_dtentropy) = buf[target];
   if(chk(ghip_get_field(Ctx, GHIP_F_MAXSIGNALVEL, buf), "ghip_get_field"))
     return -1;
-  SphP[target].MaxSignalVel = buf[target];
+  *SF64(target, Lay.s_maxsignalvel) = buf[target];
   return 0;
 }
 
@@ -1231,4 +1392,454 @@ int ngb_treefind_pairs(MyDouble searchcenter[3], MyFloat hsml, int target, int *
   (void) nexport;
   (void) nsend_local;
   return ngb_find(searchcenter, hsml, startnode, mode, 1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row N4: the black-hole neighbour passes (blackhole.c) on bound records
+ * ---------------------------------------------------------------------------------------- */
+static void fill_bh_params(ghip_bh_params *b)
+{
+  memset(b, 0, sizeof(*b));
+  double hubble_a = 1, ascale = 1;
+  if(All.ComovingIntegrationOn)   /* blackhole.c:89-95 */
+    {
+      ascale = All.Time;
+      hubble_a = hubble_function(All.Time);
+    }
+  b->BoxSize = All.BoxSize;
+  b->periodic = Cfg.periodic;
+  b->ascale = ascale;
+  b->dt_fac = All.Timebase_interval / hubble_a;   /* blackhole.c:822 */
+  b->SMBHmass = All.SMBHmass;
+  b->InnerBoundary = All.InnerBoundary;
+  b->SinkBoundary = All.SinkBoundary;
+  b->SofteningBndry = All.SofteningBndry;
+  /* blackhole.c:1099 */
+  b->CritDensity = All.CritOverDensity * All.UnitLength_in_cm * All.UnitLength_in_cm * All.UnitLength_in_cm /
+                   All.UnitMass_in_g;
+  /* blackhole.c:1138-1139 */
+  b->FeedbackCoeff = All.BlackHoleFeedbackFactor * 6.67e-8 * pow(4. * 3.1415 / 3. * 5., 0.3333) /
+                     All.UnitEnergy_in_cgs;
+  b->UnitMass_in_g = All.UnitMass_in_g;
+  b->dust = Cfg.dust;
+  b->accretion_of_dust_only = Cfg.accretion_of_dust_only;
+  b->accretion_density = Cfg.accretion_density;
+}
+
+static int bh_ready(const char *who)
+{
+  if(need_ctx(who))
+    return -1;
+  if(!Cfg.black_holes || BhLay.p_id < 0 || BhLay.p_swallowid < 0 || BhLay.p_bh_mass < 0 ||
+     BhLay.p_bh_mdot < 0 || BhLay.p_bh_density < 0 || Lay.p_hsml < 0)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "%s: needs a BLACK_HOLES configuration and records bound with "
+               "their black-hole members (gadget_force_bind_records)", who);
+      fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+      endrun(90002);
+      return -1;
+    }
+  return ensure_tree();
+}
+
+/* device marks <-> records: P[].SwallowID, SphP[].i.Injected_BH_Energy */
+static int bh_marks_to_device(void)
+{
+  unsigned int *sw = (unsigned int *) malloc((size_t) (NumPart > 0 ? NumPart : 1) * sizeof(unsigned int));
+  double *inj = (double *) malloc((size_t) (N_gas > 0 ? N_gas : 1) * sizeof(double));
+  if(!sw || !inj)
+    {
+      free(sw);
+      free(inj);
+      endrun(90003);
+      return -1;
+    }
+  for(int i = 0; i < NumPart; i++)
+    sw[i] = *(unsigned int *) (prec(i) + BhLay.p_swallowid);
+  for(int i = 0; i < N_gas; i++)
+    inj[i] = BhLay.s_injected_bh_energy >= 0 ? *SF64(i, BhLay.s_injected_bh_energy) : 0.0;
+  int rc = ghip_sink_set_marks(Ctx, sw, inj);
+  free(sw);
+  free(inj);
+  return chk(rc, "ghip_sink_set_marks") ? -1 : 0;
+}
+
+static int bh_marks_to_records(int with_mass)
+{
+  unsigned int *sw = (unsigned int *) malloc((size_t) (NumPart > 0 ? NumPart : 1) * sizeof(unsigned int));
+  double *inj = (double *) malloc((size_t) (N_gas > 0 ? N_gas : 1) * sizeof(double));
+  double *mass = with_mass ? (double *) malloc((size_t) (NumPart > 0 ? NumPart : 1) * sizeof(double)) : NULL;
+  int rc = (sw && inj && (mass || !with_mass)) ? ghip_sink_get_marks(Ctx, sw, inj) : GHIP_ENOMEM;
+  if(rc == GHIP_OK && with_mass)
+    rc = ghip_get_field(Ctx, GHIP_F_MASS, mass);
+  if(rc == GHIP_OK)
+    {
+      for(int i = 0; i < NumPart; i++)
+        {
+          *(unsigned int *) (prec(i) + BhLay.p_swallowid) = sw[i];
+          if(with_mass)
+            *PF64(i, Lay.p_mass) = mass[i];   /* blackhole.c:1290, 1312, 1330: a victim's mass becomes 0 */
+        }
+      if(BhLay.s_injected_bh_energy >= 0)
+        for(int i = 0; i < N_gas; i++)
+          *SF64(i, BhLay.s_injected_bh_energy) = inj[i];
+    }
+  free(sw);
+  free(inj);
+  free(mass);
+  return chk(rc, "ghip_sink_get_marks") ? -1 : 0;
+}
+
+/* blackhole_evaluate / _swallow of the sinks idx[0, n): results into the records */
+static int bh_evaluate_batch(int n, const int *idx)
+{
+  unsigned int *id = (unsigned int *) malloc((size_t) n * sizeof(unsigned int));
+  double *md = (double *) malloc((size_t) n * 2 * sizeof(double));
+  if(!id || !md)
+    {
+      free(id);
+      free(md);
+      endrun(90003);
+      return -1;
+    }
+  double *rho = md + n;
+  for(int k = 0; k < n; k++)
+    {
+      id[k] = *(unsigned int *) (prec(idx[k]) + BhLay.p_id);
+      md[k] = *PF64(idx[k], BhLay.p_bh_mdot);
+      rho[k] = *PF64(idx[k], BhLay.p_bh_density);
+    }
+  ghip_bh_params b;
+  fill_bh_params(&b);
+  int rc = ghip_blackhole_evaluate(Ctx, &b, n, idx, id, md, rho);
+  free(id);
+  free(md);
+  return chk(rc, "ghip_blackhole_evaluate") ? -1 : 0;
+}
+
+static int bh_swallow_batch(int n, const int *idx)
+{
+  unsigned int *id = (unsigned int *) malloc((size_t) n * sizeof(unsigned int));
+  double *buf = (double *) malloc((size_t) n * 7 * sizeof(double));
+  if(!id || !buf)
+    {
+      free(id);
+      free(buf);
+      endrun(90003);
+      return -1;
+    }
+  double *bhm = buf, *am = buf + n, *ab = buf + 2 * (size_t) n, *ad = buf + 3 * (size_t) n,
+         *mom = buf + 4 * (size_t) n;
+  for(int k = 0; k < n; k++)
+    {
+      id[k] = *(unsigned int *) (prec(idx[k]) + BhLay.p_id);
+      bhm[k] = *PF64(idx[k], BhLay.p_bh_mass);
+    }
+  ghip_bh_params b;
+  fill_bh_params(&b);
+  long long counts[3] = { 0, 0, 0 };
+  int rc = ghip_blackhole_swallow(Ctx, &b, n, idx, id, bhm, am, ab, ad, mom, counts);
+  if(rc == GHIP_OK)
+    {
+      /* blackhole.c:1337-1345 (mode 0): the sums ADD to what the sink's record holds */
+      for(int k = 0; k < n; k++)
+        {
+          const int i = idx[k];
+          *PF64(i, BhLay.p_bh_mass) = bhm[k];   /* (0 for a sink that was itself swallowed, :1312) */
+          if(BhLay.p_bh_accreted_mass >= 0)
+            *PF64(i, BhLay.p_bh_accreted_mass) += am[k];
+          if(BhLay.p_bh_accreted_bhmass >= 0)
+            *PF64(i, BhLay.p_bh_accreted_bhmass) += ab[k];
+          if(BhLay.p_bh_accreted_dustmass >= 0)
+            *PF64(i, BhLay.p_bh_accreted_dustmass) += ad[k];
+          if(BhLay.p_bh_accreted_momentum >= 0)
+            for(int c = 0; c < 3; c++)
+              PF64(i, BhLay.p_bh_accreted_momentum)[c] += mom[3 * (size_t) k + c];
+        }
+      N_gas_swallowed += (int) counts[0];
+      N_BH_swallowed += (int) counts[1];
+      N_dust_swallowed += (int) counts[2];
+    }
+  free(id);
+  free(buf);
+  return chk(rc, "ghip_blackhole_swallow") ? -1 : 0;
+}
+
+/* blackhole.c:794-1190, mode 0 */
+int blackhole_evaluate(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nexport;
+  (void) nsend_local;
+  if(bh_ready("blackhole_evaluate"))
+    return -1;
+  if(mode != 0 || target < 0 || target >= NumPart)
+    {
+      endrun(90002);
+      return -1;
+    }
+  if(bh_marks_to_device() || bh_evaluate_batch(1, &target) || bh_marks_to_records(0))
+    return -1;
+  return 0;
+}
+
+/* blackhole.c:1201-1346, mode 0 */
+int blackhole_evaluate_swallow(int target, int mode, int *nexport, int *nsend_local)
+{
+  (void) nexport;
+  (void) nsend_local;
+  if(bh_ready("blackhole_evaluate_swallow"))
+    return -1;
+  if(mode != 0 || target < 0 || target >= NumPart)
+    {
+      endrun(90002);
+      return -1;
+    }
+  if(bh_marks_to_device() || bh_swallow_batch(1, &target) || bh_marks_to_records(1))
+    return -1;
+  TreeOnDevice = 0;   /* masses changed: a tree built before is stale */
+  return 0;
+}
+
+/* the neighbour-pass core of blackhole_accretion(), blackhole.c:294-660 */
+void blackhole_accretion_neighbour_passes(void)
+{
+  if(bh_ready("blackhole_accretion"))
+    return;
+  N_gas_swallowed = N_BH_swallowed = N_dust_swallowed = 0;   /* blackhole.c:306 */
+  int n = 0;
+  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+    if(p_type(i) == 5)
+      n++;
+  /* the marks start from the records (the reference resets SwallowID at the start of a step,
+   * run.c / blackhole.c; Injected_BH_Energy accumulates until cooling consumes it) */
+  if(bh_marks_to_device())
+    return;
+  if(n > 0)
+    {
+      int *idx = (int *) malloc((size_t) n * sizeof(int));
+      if(!idx)
+        {
+          endrun(90003);
+          return;
+        }
+      int k = 0;
+      for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+        if(p_type(i) == 5)
+          idx[k++] = i;
+      int bad = bh_evaluate_batch(n, idx) || bh_swallow_batch(n, idx);
+      free(idx);
+      if(bad)
+        return;
+    }
+  if(bh_marks_to_records(1))
+    return;
+  TreeOnDevice = 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * more than one rank: the drivers as collectives over the domain-decomposed device path
+ * ---------------------------------------------------------------------------------------- */
+int gadget_force_unique_id(void *id128)
+{
+  return ghip_dd_rccl_unique_id(id128);
+}
+
+int gadget_force_connect(const void *id128)
+{
+  if(need_ctx("gadget_force_connect"))
+    return -1;
+  if(!DdReady)
+    {
+      if(chk(ghip_dd_init(Ctx, ThisTask, NTask), "ghip_dd_init"))
+        return -1;
+      DdReady = 1;
+    }
+  int rc = ghip_dd_rccl_connect(Ctx, id128);
+  if(rc == GHIP_OK)
+    RcclConnected = 1;
+  else
+    snprintf(ErrBuf, sizeof(ErrBuf), "ghip_dd_rccl_connect: %d %s", rc, ghip_last_error(Ctx));
+  return rc;
+}
+
+void gadget_force_set_allgather(int (*allgather)(void *user, const void *send, size_t bytes, void *recv),
+                                void *user)
+{
+  AllgatherFn = allgather;
+  AllgatherUser = user;
+}
+
+/* the ranks' key ranges out of the host's top-tree, the global cube, the softenings: what
+ * domain_Decomposition() left behind (domain.c:100-393) */
+static int dd_prepare(void)
+{
+  if(NTask > GHIP_DD_MAXRANKS_HOST)
+    {
+      endrun(90002);
+      return -1;
+    }
+  if(!DdReady)
+    {
+      if(chk(ghip_dd_init(Ctx, ThisTask, NTask), "ghip_dd_init"))
+        return -1;
+      DdReady = 1;
+    }
+  if(!RcclConnected && !AllgatherFn)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "NTask = %d: call gadget_force_connect() (RCCL) or "
+               "gadget_force_set_allgather() first", NTask);
+      fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+      endrun(90002);
+      return -1;
+    }
+  if(!TopNodes || !DomainStartList || NTopnodes <= 0)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "NTask = %d: TopNodes / DomainStartList of the host's domain "
+               "decomposition are not set", NTask);
+      fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+      endrun(90002);
+      return -1;
+    }
+  if(DomainLen <= 0)
+    domain_findExtent();
+  if(chk(ghip_dd_set_domain(Ctx, DomainCorner, DomainCenter, DomainLen, All.ForceSoftening),
+         "ghip_dd_set_domain"))
+    return -1;
+  unsigned long long splits[GHIP_DD_MAXRANKS_HOST + 1];
+  for(int r = 0; r < NTask; r++)
+    {
+      splits[r] = ~0ULL;
+      for(int i = 0; i < NTopnodes; i++)   /* the top-leaf DomainStartList[r] (domain.c:1495-1509) */
+        if(TopNodes[i].Daughter == -1 && TopNodes[i].Leaf == DomainStartList[r])
+          {
+            splits[r] = TopNodes[i].StartKey;
+            break;
+          }
+      if(splits[r] == ~0ULL)
+        {
+          snprintf(ErrBuf, sizeof(ErrBuf), "no top-leaf %d (DomainStartList[%d]) in TopNodes",
+                   DomainStartList[r], r);
+          fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+          endrun(90002);
+          return -1;
+        }
+    }
+  splits[0] = 0;
+  splits[NTask] = 1ULL << (3 * BITS_PER_DIMENSION);   /* PEANOCELLS */
+  return chk(ghip_dd_set_splits(Ctx, splits), "ghip_dd_set_splits") ? -1 : 0;
+}
+
+/* one collective operation of the state machine: over RCCL, or staged through the host's all-gather */
+static int dd_collective(int op, const void *params, int walk, const char *what)
+{
+  if(RcclConnected && !AllgatherFn)
+    return chk(ghip_dd_run(Ctx, op, params, walk), what) ? -1 : 0;
+  if(chk(ghip_dd_begin(Ctx, op, params, walk), what))
+    return -1;
+  for(;;)
+    {
+      int r = ghip_dd_step(Ctx);
+      if(r == 0)
+        return 0;
+      if(r < 0)
+        return chk(r, what) ? -1 : 0;
+      if(chk(ghip_dd_exchange_host(Ctx, AllgatherFn, AllgatherUser), what))
+        return -1;
+    }
+}
+
+static int set_active_list(int nact, int everybody)
+{
+  if(everybody)
+    return chk(ghip_set_active(Ctx, NULL, 0), "ghip_set_active") ? -1 : 0;
+  return chk(ghip_set_active(Ctx, ActiveBuf ? ActiveBuf : &nact, nact), "ghip_set_active") ? -1 : 0;
+}
+
+/* gravtree.c:27-828 on NTask ranks: the local walk + the export rounds :175-339 become one pass of the
+ * domain-decomposed device path (this rank's tree, the others' locally essential trees, one merged
+ * tree, the walks); every target meets the interaction set of the reference's single global tree */
+static void gravity_tree_ranks(void)
+{
+  double t0 = wallclock();
+  if(All.ComovingIntegrationOn)
+    set_softenings();
+  DeviceFresh = 0;
+  TreeOnDevice = 0;
+  GravPending = 0;
+  int nact = collect_active(0);
+  if(nact < 0)
+    return;
+  if(upload_particles(0))
+    return;
+  if(dd_prepare())
+    return;
+  if(set_active_list(nact, nact == NumPart))
+    return;
+  ghip_grav_params g;
+  fill_grav_params(&g);
+  int walk = Cfg.pmgrid ? GHIP_WALK_SHORTRANGE : GHIP_WALK_NEWTON;
+  if(Cfg.periodic && !Cfg.pmgrid)
+    walk = GHIP_WALK_NEWTON_EWALD;
+  if(dd_collective(GHIP_DD_GRAVITY, &g, walk, "gravity_tree (ranks)"))
+    return;
+  TreeOnDevice = 1;
+  TreeReconstructFlag = 0;
+  GravPendingActive = nact;
+  if(gravity_complete(1))
+    return;
+  Phase = 1;
+  CPU_Step_Treewalk += wallclock() - t0;
+}
+
+/* density.c:89-704 on NTask ranks: the export rounds :193-389 become an import of ghost gas
+ * particles; the h iteration then runs without another exchange */
+static void density_ranks(void)
+{
+  double t0 = wallclock();
+  if(Phase != 1)
+    {
+      DeviceFresh = 0;
+      if(upload_particles(0) || dd_prepare())
+        return;
+    }
+  int nact = collect_active(1);
+  if(nact < 0)
+    return;
+  int nact_all = 0;
+  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
+    nact_all++;
+  if(set_active_list(nact, nact_all == NumPart))
+    return;
+  ghip_dens_params d;
+  fill_dens_params(&d);
+  if(dd_collective(GHIP_DD_DENSITY, &d, 0, "density (ranks)"))
+    return;
+  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos"))
+    return;
+  /* (sink / dust density targets on ranks: GHIP_DD_SINK_DENSITY, through the ghip_dd_* interface) */
+  Phase = 2;
+  CPU_Step_Density += wallclock() - t0;
+}
+
+/* hydra.c:145-813 on NTask ranks: the ghosts carry their owners' density results (refreshed at the end
+ * of density()), so the pass itself is local */
+static void hydro_force_ranks(void)
+{
+  double t0 = wallclock();
+  if(Phase != 2)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "hydro_force on %d ranks must follow density() and "
+               "force_update_hmax() of the same step (accel.c:84-106)", NTask);
+      fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+      endrun(90002);
+      return;
+    }
+  ghip_hydro_params h;
+  fill_hydro_params(&h, 0);
+  if(dd_collective(GHIP_DD_HYDRO, &h, 0, "hydro_force (ranks)"))
+    return;
+  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 0, 1), "ghip_download_aos"))
+    return;
+  Phase = 0;
+  CPU_Step_Hydro += wallclock() - t0;
 }

@@ -59,13 +59,38 @@ class AllStruct(C.Structure):
                 ("MaxSizeTimestep", C.c_double), ("MinSizeTimestep", C.c_double),
                 ("MaxRMSDisplacementFac", C.c_double), ("OmegaBaryon", C.c_double),
                 ("MinEgySpec", C.c_double), ("TypeOfTimestepCriterion", C.c_int),
-                ("StarformationOn", C.c_int)]
+                ("StarformationOn", C.c_int),
+                ("BlackHoleNgbFactor", C.c_double), ("BlackHoleFeedbackFactor", C.c_double),
+                ("SMBHmass", C.c_double), ("InnerBoundary", C.c_double),
+                ("SinkBoundary", C.c_double), ("CritOverDensity", C.c_double),
+                ("UnitLength_in_cm", C.c_double), ("UnitMass_in_g", C.c_double),
+                ("UnitEnergy_in_cgs", C.c_double)]
 
 
 class Config(C.Structure):
     _fields_ = [("periodic", C.c_int), ("pmgrid", C.c_int), ("unequal_softenings", C.c_int),
                 ("device", C.c_int), ("black_holes", C.c_int), ("dust", C.c_int),
+                ("accretion_of_dust_only", C.c_int), ("accretion_density", C.c_int),
                 ("overlap_sph", C.c_int)]
+
+
+class BhLayout(C.Structure):
+    """struct gadget_force_bh_layout: byte offsets of the members the sink passes touch (-1: absent)"""
+    _fields_ = [(k, C.c_int) for k in (
+        "p_id", "p_swallowid", "p_bh_mass", "p_bh_mdot", "p_bh_density", "p_bh_entropy",
+        "p_bh_gasvel", "p_bh_accreted_mass", "p_bh_accreted_bhmass", "p_bh_accreted_dustmass",
+        "p_bh_accreted_momentum", "p_dust_density", "p_dust_entropy", "p_dust_gasvel",
+        "p_dust_mass", "s_injected_bh_energy")]
+
+
+class TopNode(C.Structure):
+    """struct topnode_data, allvars.h:437-447"""
+    _fields_ = [("Size", C.c_ulonglong), ("StartKey", C.c_ulonglong), ("Count", C.c_longlong),
+                ("GravCost", C.c_double), ("Daughter", C.c_int), ("Pstart", C.c_int),
+                ("Blocks", C.c_int), ("Leaf", C.c_int)]
+
+
+HOST_ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 ENDRUN_CB = C.CFUNCTYPE(None, C.c_int)
@@ -86,7 +111,9 @@ ALL_MEMBERS = [
     ("BufferSize", "f8"), ("ErrTolIntAccuracy", "f8"), ("CourantFac", "f8"),
     ("MaxSizeTimestep", "f8"), ("MinSizeTimestep", "f8"), ("MaxRMSDisplacementFac", "f8"),
     ("OmegaBaryon", "f8"), ("MinEgySpec", "f8"), ("TypeOfTimestepCriterion", "i4"),
-    ("StarformationOn", "i4")]
+    ("StarformationOn", "i4"), ("BlackHoleNgbFactor", "f8"), ("BlackHoleFeedbackFactor", "f8"),
+    ("SMBHmass", "f8"), ("InnerBoundary", "f8"), ("SinkBoundary", "f8"), ("CritOverDensity", "f8"),
+    ("UnitLength_in_cm", "f8"), ("UnitMass_in_g", "f8"), ("UnitEnergy_in_cgs", "f8")]
 
 EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
            "gadget_force_init", "gadget_force_finalize", "gadget_force_last_error",
@@ -105,7 +132,12 @@ EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
            "gadget_force_set_kick_tables", "TimeBinCount", "TimeBinCountSph", "TimeBinActive",
            "FirstInTimeBin", "LastInTimeBin", "NextInTimeBin", "PrevInTimeBin", "Flag_FullStep",
            "Nodes_base", "Nodes", "Extnodes_base", "Extnodes", "Nextnode", "Father", "MaxNodes",
-           "Numnodestree"]
+           "Numnodestree",
+           "gadget_force_bind_records", "blackhole_evaluate", "blackhole_evaluate_swallow",
+           "blackhole_accretion_neighbour_passes", "N_gas_swallowed", "N_BH_swallowed",
+           "N_dust_swallowed", "TopNodes", "NTopnodes", "NTopleaves", "DomainStartList",
+           "DomainEndList", "gadget_force_unique_id", "gadget_force_connect",
+           "gadget_force_set_allgather", "ThisTask", "NTask", "gadget_force_flush"]
 
 _LIB = None
 
@@ -143,6 +175,15 @@ def lib():
         L.morton_key.restype = C.c_ulonglong
         L.hubble_function.argtypes = [C.c_double]
         L.hubble_function.restype = C.c_double
+        L.gadget_force_bind_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gadget_force_bind_records.restype = None
+        for f in ("blackhole_evaluate", "blackhole_evaluate_swallow"):
+            getattr(L, f).argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.blackhole_accretion_neighbour_passes.restype = None
+        L.gadget_force_unique_id.argtypes = [C.c_void_p]
+        L.gadget_force_connect.argtypes = [C.c_void_p]
+        L.gadget_force_set_allgather.argtypes = [HOST_ALLGATHER_CB, C.c_void_p]
+        L.gadget_force_set_allgather.restype = None
         _LIB = L
     return _LIB
 
@@ -152,12 +193,15 @@ class Host:
     and points the library's globals at them."""
 
     def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0, black_holes=0, dust=0,
-                 overlap_sph=0):
+                 overlap_sph=0, accretion_of_dust_only=0, accretion_density=0, rank=0, nranks=1):
         self.L = lib()
         self.endrun_codes = []
         self._cb = ENDRUN_CB(lambda code: self.endrun_codes.append(code))
         self.L.gadget_force_set_endrun(self._cb)
-        cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust, overlap_sph)
+        self._seti("ThisTask", rank)
+        self._seti("NTask", nranks)
+        cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust, accretion_of_dust_only,
+                     accretion_density, overlap_sph)
         rc = self.L.gadget_force_init(C.byref(cfg))
         if rc != 0:
             raise RuntimeError("gadget_force_init failed (%d): %s" %
@@ -176,8 +220,57 @@ class Host:
         self._bound = (host_all, tab)            # keep both alive
         self.L.gadget_force_bind_all(C.c_void_p(host_all.ctypes.data), tab)
 
+    def bind_records(self, P, SphP, lay, bh=None):
+        """gadget_force_bind_records: the host's own record arrays (any numpy structured dtype) by
+        byte offsets -- `lay` a bindings.Layout, `bh` a BhLayout or None"""
+        self.P, self.SphP = P, SphP
+        self._rec = (P, SphP, lay, bh)          # keep alive
+        self.L.gadget_force_bind_records(
+            C.c_void_p(P.ctypes.data), C.c_void_p(SphP.ctypes.data) if SphP is not None else None,
+            C.cast(C.byref(lay), C.c_void_p), C.cast(C.byref(bh), C.c_void_p) if bh is not None else None)
+        self._seti("NumPart", len(P))
+        self._seti("N_gas", 0 if SphP is None else len(SphP))
+        self.All.MaxPart = len(P)
+        self.L.gadget_force_mark_dirty()
+        self._seti("TreeReconstructFlag", 1)
+
+    def set_allgather(self, allgather):
+        """the host's all-gather for more than one rank: allgather(send: bytes) -> bytes of all ranks"""
+        def cb(_user, send, nbytes, recv):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:   # noqa: BLE001 -- reported through the C return code
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._agcb = HOST_ALLGATHER_CB(cb)
+        self.L.gadget_force_set_allgather(self._agcb, None)
+
+    def set_topnodes(self, start_keys, sizes, start_list, end_list):
+        """the host's domain decomposition as the drivers read it: top-leaves in key order and the
+        leaf ranges of the ranks (TopNodes / DomainStartList / DomainEndList, allvars.h:424-449)"""
+        nleaf = len(start_keys)
+        arr = (TopNode * nleaf)()
+        for i in range(nleaf):
+            arr[i].Size, arr[i].StartKey = int(sizes[i]), int(start_keys[i])
+            arr[i].Daughter, arr[i].Leaf = -1, i
+        self._top = arr
+        self._dstart = np.ascontiguousarray(start_list, np.int32)
+        self._dend = np.ascontiguousarray(end_list, np.int32)
+        C.c_void_p.in_dll(self.L, "TopNodes").value = C.addressof(arr)
+        self._seti("NTopnodes", nleaf)
+        self._seti("NTopleaves", nleaf)
+        self._setp("DomainStartList", self._dstart)
+        self._setp("DomainEndList", self._dend)
+
     def close(self):
         self.L.gadget_force_bind_all(None, None)
+        self.L.gadget_force_bind_records(None, None, None, None)
+        self.L.gadget_force_set_allgather(C.cast(None, HOST_ALLGATHER_CB), None)
+        self._seti("ThisTask", 0)
+        self._seti("NTask", 1)
         self.L.gadget_force_finalize()
 
     def _setp(self, name, arr):

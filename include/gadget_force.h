@@ -148,6 +148,10 @@ struct global_data_all_processes
   double ErrTolIntAccuracy, CourantFac, MaxSizeTimestep, MinSizeTimestep, MaxRMSDisplacementFac;
   double OmegaBaryon, MinEgySpec;
   int TypeOfTimestepCriterion, StarformationOn;
+  /* "next" row N4: the sink passes (blackhole.c, density.c BLACK_HOLES / DUST branches) */
+  double BlackHoleNgbFactor, BlackHoleFeedbackFactor;
+  double SMBHmass, InnerBoundary, SinkBoundary, CritOverDensity;
+  double UnitLength_in_cm, UnitMass_in_g, UnitEnergy_in_cgs;
 };
 
 /* A host whose `All` is the reference's full struct (allvars.h:530-1123, ~300 members whose
@@ -168,7 +172,9 @@ struct global_data_all_processes
   X(SofteningBndryMaxPhys) X(SofteningTable) X(ForceSoftening) X(Rcut) X(Asmth)                   \
   X(TotNumOfForces) X(BunchSize) X(BufferSize) X(ErrTolIntAccuracy) X(CourantFac)                 \
   X(MaxSizeTimestep) X(MinSizeTimestep) X(MaxRMSDisplacementFac) X(OmegaBaryon) X(MinEgySpec)     \
-  X(TypeOfTimestepCriterion) X(StarformationOn)
+  X(TypeOfTimestepCriterion) X(StarformationOn) X(BlackHoleNgbFactor) X(BlackHoleFeedbackFactor)  \
+  X(SMBHmass) X(InnerBoundary) X(SinkBoundary) X(CritOverDensity) X(UnitLength_in_cm)             \
+  X(UnitMass_in_g) X(UnitEnergy_in_cgs)
 struct gadget_force_all_layout
 {
 #define GADGET_FORCE_X(m) int m;
@@ -179,6 +185,26 @@ struct gadget_force_all_layout
  * the reference's (int / double / long long, MyFloat == double: DOUBLEPRECISION builds). */
 void gadget_force_bind_all(void *host_All, const struct gadget_force_all_layout *offsets);
 int gadget_force_all_layout_count(void);   /* number of ints in the table (ABI check for bindings) */
+
+/* A host built with another -D set keeps its own struct particle_data / sph_particle_data -- the
+ * shipped bundle's are 536 / 264 bytes, with Hsml and NumNgb in P (the PPP macro) and the
+ * BLACK_HOLES / DUST unions -- and binds its arrays by BYTE OFFSETS: every driver of this library then
+ * reads and writes the host's records through the tables (P / SphP below stay unused).  `lay` as for
+ * ghip_upload_aos; `bh` (may be NULL) names the members the sink passes touch, -1 = absent:
+ *   P[].ID, SwallowID (unsigned int), BH_Mass, BH_Mdot, b1.BH_Density, b2.BH_Entropy,
+ *   b3.BH_SurroundingGasVel[3], b4.BH_accreted_Mass, b5.BH_accreted_BHMass, b5.BH_accreted_DustMass,
+ *   b6.BH_accreted_momentum[3], d1.DUST_Density, d2.DUST_Entropy, d3.DUST_SurroundingGasVel[3],
+ *   Dust_Mass (allvars.h:1206-1330), SphP[].i.Injected_BH_Energy (allvars.h:1580-1584).
+ * A probe TU fills both tables with offsetof() under the host's flags. */
+struct gadget_force_bh_layout
+{
+  int p_id, p_swallowid, p_bh_mass, p_bh_mdot, p_bh_density, p_bh_entropy, p_bh_gasvel;
+  int p_bh_accreted_mass, p_bh_accreted_bhmass, p_bh_accreted_dustmass, p_bh_accreted_momentum;
+  int p_dust_density, p_dust_entropy, p_dust_gasvel, p_dust_mass;
+  int s_injected_bh_energy;
+};
+void gadget_force_bind_records(void *host_P, void *host_SphP, const ghip_layout *lay,
+                               const struct gadget_force_bh_layout *bh);   /* host_P == NULL unbinds */
 
 /* allvars.h:1673-1684: export bookkeeping record other translation units sort with the two
  * functions below (blackhole.c:366, dust.c:114, density.c:186 ...) */
@@ -244,6 +270,8 @@ struct gadget_force_config
   int black_holes;         /* -DBLACK_HOLES (without NO_BH_ACCRETION): Type 5 is a density target
                               (density.c:1035-1041) */
   int dust;                /* -DDUST: Type 2 is a density target (density.c:1043-1046) */
+  int accretion_of_dust_only;   /* -DACCRETION_OF_DUST_ONLY (blackhole.c:1003) */
+  int accretion_density;        /* -DACCRETION_DENSITY (blackhole.c:1094) */
   int overlap_sph;         /* 1: on a step with gas, gravity_tree() returns with its walks still in
                               flight and density() / force_update_hmax() / hydro_force() run underneath
                               them on the device; the gravity results (GravAccel, OldAcc, GravCost)
@@ -332,6 +360,50 @@ int ngb_treefind_variable(MyDouble searchcenter[3], MyFloat hsml, int target, in
                           int mode, int *nexport, int *nsend_local);
 int ngb_treefind_pairs(MyDouble searchcenter[3], MyFloat hsml, int target, int *startnode,
                        int mode, int *nexport, int *nsend_local);
+
+/* "next" row N4, BLACK_HOLES builds with bound records (gadget_force_bind_records with a bh table):
+ * the two per-sink neighbour passes with the reference's signatures (proto.h:110-111; mode 0 = a
+ * local sink, index into P[]) -- a batch of one on the device -- and the neighbour-pass core of
+ * blackhole_accretion() (blackhole.c:70): for ALL active sinks, SwallowID / Injected_BH_Energy reset
+ * (:300-305 via the marks), blackhole_evaluate (:346-353), blackhole_evaluate_swallow (:545-551), the
+ * accreted sums added to the sinks' records (:648-660), the victims' Mass zeroed, and the swallow
+ * counts (N_gas_swallowed, N_BH_swallowed, N_dust_swallowed).  The per-sink scalar bookkeeping
+ * around it (Mdot, Eddington limit, logs: blackhole.c:133-290, 690-800) stays the host's. */
+int blackhole_evaluate(int target, int mode, int *nexport, int *nsend_local);
+int blackhole_evaluate_swallow(int target, int mode, int *nexport, int *nsend_local);
+void blackhole_accretion_neighbour_passes(void);
+extern int N_gas_swallowed, N_BH_swallowed, N_dust_swallowed;
+
+/* ---- more than one rank (NTask > 1): the drivers above become collectives ----
+ * The host has decomposed the domain (domain_Decomposition, domain.c:100) and every rank holds the
+ * particles of its key range in P[0, NumPart).  With NTask > 1 gravity_tree() / density() /
+ * force_update_hmax() / hydro_force() take the ranks' key ranges from the host's own top-tree
+ *   splits[r] = TopNodes[<the leaf DomainStartList[r]>].StartKey          (domain.c:1075-1113, 1495)
+ * and run the domain-decomposed device path (ghip_dd_*: locally essential trees and SPH ghosts in
+ * place of the export loops gravtree.c:175-339, density.c:193-389, hydra.c:274-526 and of the
+ * pseudo-particle exchange forcetree.c:879-1016, 1722-1747).  MULTIPLEDOMAINS must be 1.
+ * Exchanges go over RCCL (gadget_force_connect: every rank passes the 128-byte id that rank 0
+ * obtained from gadget_force_unique_id and broadcast over the host's MPI), or -- a host without
+ * RCCL, several ranks on one GPU -- through the host's own all-gather (gadget_force_set_allgather:
+ * `allgather(user, send, bytes, recv)` = MPI_Allgather(send, bytes, MPI_BYTE, recv, bytes, MPI_BYTE)). */
+struct topnode_data   /* allvars.h:437-447 */
+{
+  peanokey Size;
+  peanokey StartKey;
+  long long Count;
+  MyFloat GravCost;
+  int Daughter;
+  int Pstart;
+  int Blocks;
+  int Leaf;
+};
+extern struct topnode_data *TopNodes;
+extern int NTopnodes, NTopleaves;
+extern int *DomainStartList, *DomainEndList;
+int gadget_force_unique_id(void *id128);
+int gadget_force_connect(const void *id128);
+void gadget_force_set_allgather(int (*allgather)(void *user, const void *send, size_t bytes, void *recv),
+                                void *user);
 
 peanokey peano_hilbert_key(int x, int y, int z, int bits);
 peanokey morton_key(int x, int y, int z, int bits);

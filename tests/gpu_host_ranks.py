@@ -1,0 +1,140 @@
+"""Rank program of tests/test_gpu_boundary.py::test_four_call_sequence_on_two_ranks_...: run under
+torch.distributed.run, one process per rank, all ranks on GPU 0.
+
+Every rank builds the same seeded problem, keeps the particles of its Peano-Hilbert key range as
+536 / 264-byte records (the shipped bundle's layout, bound by byte offsets), describes the
+decomposition the way domain_Decomposition leaves it (TopNodes[] leaves in key order,
+DomainStartList / DomainEndList per rank) and calls accel.c's sequence through the reference-named
+symbols of libgadget_force.so with NTask = world size: gravity_tree() x 2, density(),
+force_update_hmax(), hydro_force().  Exchanges go through the host's all-gather (gloo).  Rank 0
+gathers the records and checks them against the oracle's single global tree; prints one JSON line."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from common import O, SinkProblem, bindings, relerr
+    import test_gpu_boundary as TB
+    B = bindings()
+    H = importlib.import_module("gadget-leicester_amd.hostapi")
+    S = importlib.import_module("gadget-leicester_amd.sharded")
+
+    sp = SinkProblem(ng=12, periodic=1, nsink=5, ndust=100)
+    pr = sp.pr
+    n, ng = pr.n, pr.ngas
+    eps = pr.force_soft[0] / 2.8
+
+    # the decomposition: a histogram of the keys over the cells of one level, cut by
+    # domain_findSplit_work_balanced (ghip_dd_find_split), as sharded.decompose does -- kept here as
+    # TopNodes leaves + DomainStartList / DomainEndList, which is what the drivers read
+    probe = B.ForcePath(0)
+    probe.set_counts(n, 0)
+    probe.set_field(B.F_POS, pr.ic["pos"])
+    probe.dd_init(0, 1)
+    probe.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+    keys = probe.dd_keys()
+    probe.close()
+    level = S.histogram_level(n)
+    while 8 ** level < world:
+        level += 1
+    shift = np.uint64(63 - 3 * level)
+    cell = (keys >> shift).astype(np.int64)
+    hist = np.bincount(cell, minlength=8 ** level).astype(np.float64)
+    start, end = B.dd_find_split(world, hist)
+    leaf_keys = (np.arange(8 ** level, dtype=np.uint64) << shift)
+    leaf_size = np.full(8 ** level, np.uint64(1) << shift, np.uint64)
+    owner = np.searchsorted(np.asarray(start[1:], np.int64), cell, side="right")
+    mine = np.where(owner == rank)[0]
+    gid = np.concatenate([mine[mine < ng], mine[mine >= ng]])
+
+    lay, bh = TB.bundle_layouts(B, H)
+    P, Sp = TB.bundle_records(sp, gid)
+    host = H.Host(periodic=1, rank=rank, nranks=world)
+
+    def allgather(data):
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        out = torch.empty(world * len(data), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, t)
+        return out.numpy().tobytes()
+
+    ok, err = True, ""
+    try:
+        host.set_allgather(allgather)
+        host.bind_records(P, Sp, lay, bh)
+        TB.set_all(host, sp, eps)
+        host.set_topnodes(leaf_keys, leaf_size, start, end)
+        host.set_active(None)
+        host.domain()            # the extent of ALL ranks (domain.c:1996-1997)
+        L = host.L
+        L.gravity_tree()
+        L.gravity_tree()
+        L.density()
+        L.force_update_hmax()
+        L.hydro_force()
+        if host.endrun_codes:
+            ok, err = False, "endrun %r: %s" % (host.endrun_codes, L.gadget_force_last_error().decode())
+    except Exception as e:   # noqa: BLE001
+        ok, err = False, repr(e)
+
+    # gather the records on rank 0
+    blob = [None] * world
+    dist.all_gather_object(blob, (ok, err, gid, P.tobytes(), Sp.tobytes()))
+    out = None
+    if rank == 0:
+        ok = all(b[0] for b in blob)
+        err = "; ".join(b[1] for b in blob if b[1])
+        out = {"ok": ok, "error": err, "particles_expected": n}
+        if ok:
+            Pg = np.zeros(n, TB.P536)
+            Sg = np.zeros(ng, TB.S264)
+            seen = 0
+            for _ok, _e, g, pb, sb in blob:
+                Pr = np.frombuffer(pb, TB.P536)
+                Sr = np.frombuffer(sb, TB.S264)
+                Pg[g] = Pr
+                Sg[g[g < ng]] = Sr
+                seen += len(g)
+            out["particles"] = seen
+            T = O.Tree(pr.ic["pos"], pr.ic["vel"], pr.ic["mass"], pr.ic["type"], pr.force_soft,
+                       hsml=sp.hsml, extent=pr.extent)
+            tg = np.arange(n, dtype=np.int32)
+            tab = O.ewald_table(pr.box)
+            a0, c0 = T.gravity(pr.o_grav(pr.theta), tg, np.zeros(n))
+            T.gravity_ewald_add(pr.o_grav(pr.theta), tab, tg, np.zeros(n), a0, c0)
+            old = np.linalg.norm(a0, axis=1)
+            a1, c1 = T.gravity(pr.o_grav(0.0), tg, old)
+            T.gravity_ewald_add(pr.o_grav(0.0), tab, tg, old, a1, c1)
+            out["counts_equal"] = bool(np.array_equal(Pg["GravCost"].astype(np.int64), c1))
+            out["rel_acc"] = float(relerr(Pg["GravAccel"], pr.G * a1))
+            act = np.arange(ng, dtype=np.int32)
+            od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                           pr.ti_begstep, sp.hsml)
+            out["rel_density"] = float(max(relerr(Sg["Density"], od["density"][:ng]),
+                                           relerr(Pg["Hsml"][:ng], od["hsml"][:ng])))
+            T.update_hmax(act, od["hsml"], od["divvel"])
+            oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
+                         od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
+            out["rel_hydro"] = float(np.abs(Sg["HydroAccel"] - oh["hydroaccel"][:ng]).max() /
+                                     np.abs(oh["hydroaccel"]).max())
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    host.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

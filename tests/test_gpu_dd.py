@@ -520,6 +520,48 @@ def test_bench_ranks_share_one_gpu_through_the_host_transport(nranks):
     assert out["work_per_step_rank0"]["grav_interactions"] > 0
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_ranks_exchange_through_the_rccl_entry_points(nranks):
+    """The RCCL branch of the exchanges -- ncclAllGather of the counts, then ONE group of ncclSend /
+    ncclRecv (ghip_dd_exchange, csrc/ghip_comm.hip) -- with more than one rank.  The real RCCL refuses
+    several ranks on one device, and this box has one: the nine entry points the library binds are
+    supplied by tests/mock_rccl (shared memory between the rank processes), selected with
+    GHIP_RCCL_LIB.  Same bench, same checks as over the host transport, and the run must report that
+    it went through the RCCL entry points -- and agree, interaction for interaction, with the run
+    staged through the host."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "tests", "mock_rccl", "librccl_mock.so")
+    assert os.path.exists(mock), "build tests/mock_rccl first (__graft_entry__.build())"
+    res = {}
+    for transport in ("rccl", "host"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, BENCH_TRANSPORT=transport, MASTER_ADDR="127.0.0.1", GHIP_RCCL_LIB=mock)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+               "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--ng", "20"]
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        res[transport] = json.loads(lines[0])
+    out = res["rccl"]
+    assert out["transport"] == "rccl" and out["rccl_library"].endswith("librccl_mock.so"), out.get("transport")
+    assert res["host"]["transport"] == "host"
+    assert out["n_gpus"] == nranks and out["config"]["n_particles"] == 2 * 20 ** 3
+    x = out["exchange_per_step_rank0"]
+    assert x["bytes_sent_tree_nodes"] > 0 and x["bytes_sent_ghosts"] > 0
+    for k in ("grav_interactions", "ewald_interactions", "dens_neighbours", "hydro_pairs"):
+        assert out["work_per_step_rank0"][k] == res["host"]["work_per_step_rank0"][k] > 0, k
+    assert x == res["host"]["exchange_per_step_rank0"]
+
+
 def test_hydro_release_variants_do_the_same_work():
     """When the hydro kernel is let go underneath a gravity pair is scheduling only: on the word the
     Ewald walk sets when its last workgroup starts (default, hipStreamWaitValue32), on the walk's end
