@@ -216,7 +216,6 @@ def main():
             dom = S.DomainRank(fp, rank, world, bcast, transport="host", allgather=allgather_bytes)
         fp.dd_set_domain(*tree_args)
         fp.dd_set_splits(splits)
-        fp.dd_set_ghost_margin(1.5)
         parallelism = ("Peano-Hilbert domain decomposition over %d GPUs: migration, locally "
                        "essential trees and SPH ghosts over RCCL (%s), one merged tree per rank"
                        % (world, "NOT AVAILABLE (%s): exchanges staged through the host + gloo"

@@ -339,7 +339,7 @@ static int build_groups(ghip_ctx *ctx, bool gas, const int *tgt, int nt)
 {
   DDState &D = ctx->dd;
   hipStream_t st = ctx->stream;
-  GCHK(ghip_ensure(ctx, D.grp_own, (size_t) DD_TABLE * sizeof(DDGroup)));
+  GCHK(ghip_ensure(ctx, D.grp_own, (size_t) DD_STRIDE * sizeof(DDGroup)));
   DDGroup *tab = P<DDGroup>(D.grp_own);
   int gsz = (nt + DD_NGROUPS - 1) / DD_NGROUPS;
   if(gsz < 1)
@@ -347,9 +347,47 @@ static int build_groups(ghip_ctx *ctx, bool gas, const int *tgt, int nt)
   k_dd_groups<<<DD_NGROUPS, 64, 0, st>>>(nt, gsz, tgt, P<double>(ctx->sx), P<double>(ctx->sy),
                                          P<double>(ctx->sz), P<int>(ctx->gt.perm),
                                          P<double>(ctx->f[gas ? GHIP_F_HSML : GHIP_F_OLDACC]),
-                                         gas ? D.gh_margin : 1.0, tab);
+                                         gas ? D.gh_margin_cur : 1.0, tab);
   k_dd_supergroups<<<DD_NSUPER, 64, 0, st>>>(tab);
   HIPCHK(hipGetLastError());
+  // the status record behind the table: has anything gone wrong on this shard so far?  (The error,
+  // if any, is kept: after the all-gather every shard fails, this one with its own message.)
+  HIPCHK(ghip_stream_sync(ctx, st));
+  D.local_err = ghip_check_device_errors(ctx);
+  if(D.local_err != GHIP_OK)
+    D.local_msg = ctx->err;
+  DDGroup status;
+  memset(&status, 0, sizeof(status));
+  status.cx = D.local_err != GHIP_OK ? 1.0 : 0.0;
+  HIPCHK(hipMemcpyAsync(tab + DD_TABLE, &status, sizeof(status), hipMemcpyHostToDevice, st));
+  HIPCHK(ghip_stream_sync(ctx, st));   // (`status` lives on this frame)
+  return GHIP_OK;
+}
+
+// after the all-gather of the group tables: did every shard get this far without an error?
+__global__ void k_dd_collect_status(int nranks, const DDGroup *__restrict__ all, double *__restrict__ out)
+{
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if(r < nranks)
+    out[r] = all[(size_t) r * DD_STRIDE + DD_TABLE].cx;
+}
+
+static int check_group_status(ghip_ctx *ctx, const char *what)
+{
+  DDState &D = ctx->dd;
+  hipStream_t st = ctx->stream;
+  const int P_ = D.nranks;
+  GCHK(ghip_ensure(ctx, D.status_all, (size_t) GHIP_MAXRANKS * 2 * 8));
+  k_dd_collect_status<<<1, 64, 0, st>>>(P_, P<DDGroup>(D.grp_all), P<double>(D.status_all));
+  double flags[GHIP_MAXRANKS];
+  HIPCHK(hipMemcpyAsync(flags, D.status_all.p, (size_t) P_ * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ghip_stream_sync(ctx, st));
+  if(D.local_err != GHIP_OK)
+    return ghip_fail(ctx, D.local_err, "%s", D.local_msg.c_str());
+  for(int r = 0; r < P_; r++)
+    if(flags[r] != 0)
+      return ghip_fail(ctx, GHIP_EDEVICE, "%s: shard %d reported an error while it prepared its target "
+                       "groups (its own message says what); every shard stops here", what, r);
   return GHIP_OK;
 }
 
@@ -496,7 +534,7 @@ k_let_level(int nelem, int level, const int4 *__restrict__ lk, const double4 *__
       unsigned long long cm = __ballot(test && ((r >> b) & 1ULL));
       if(cm == 0)
         continue;
-      const DDGroup *tab = groups + (size_t) b * DD_TABLE;
+      const DDGroup *tab = groups + (size_t) b * DD_STRIDE;
       const DDGroup Gs = tab[lane];
       while(cm)
         {
@@ -842,7 +880,7 @@ k_ghost_select(int nsrc, const int *__restrict__ src, const int *__restrict__ pe
                cz = rz + 0.5 * (lo[2] + hi[2]);
   const double ex = 0.5 * (hi[0] - lo[0]) * (1 + 1e-12) + 1e-14, ey = 0.5 * (hi[1] - lo[1]) * (1 + 1e-12) + 1e-14,
                ez = 0.5 * (hi[2] - lo[2]) * (1 + 1e-12) + 1e-14;
-  const DDGroup *tab = groups + (size_t) b * DD_TABLE;
+  const DDGroup *tab = groups + (size_t) b * DD_STRIDE;
   unsigned long long sm = __ballot(d_group_near_box(tab[lane], cx, cy, cz, ex, ey, ez, hm, K));
   bool need = false;
   while(sm)
@@ -977,12 +1015,13 @@ static int gravity_step(ghip_ctx *ctx)
       GCHK(ghip_tree_build_impl(ctx));
       GCHK(ghip_build_target_lists(ctx));
       GCHK(build_groups(ctx, false, P<int>(ctx->tg_grav), ctx->nt_grav));
-      set_allgather(D, D.grp_own.p, (size_t) DD_TABLE * sizeof(DDGroup), &D.grp_all);
+      set_allgather(D, D.grp_own.p, (size_t) DD_STRIDE * sizeof(DDGroup), &D.grp_all);
       D.phase = 1;
       return 1;
     }
   if(D.phase == 1)
     {
+      GCHK(check_group_status(ctx, "gravity"));   // (all shards together, see DD_STRIDE)
       // what can the others need of this tree?
       TreeDev &t = ctx->gt;
       int scount[GHIP_MAXRANKS], soff[GHIP_MAXRANKS], total = 0;
@@ -1098,12 +1137,13 @@ static int density_step(ghip_ctx *ctx)
           HIPCHK(ghip_stream_sync(ctx, st));
         }
       GCHK(build_groups(ctx, true, P<int>(D.gas_tgt), ngt));
-      set_allgather(D, D.grp_own.p, (size_t) DD_TABLE * sizeof(DDGroup), &D.grp_all);
+      set_allgather(D, D.grp_own.p, (size_t) DD_STRIDE * sizeof(DDGroup), &D.grp_all);
       D.phase = 1;
       return 1;
     }
   if(D.phase == 1)
     {
+      GCHK(check_group_status(ctx, "density"));
       // which local gas particles are ghosts where
       int total = 0;
       for(int r = 0; r < GHIP_MAXRANKS; r++)
@@ -1116,7 +1156,7 @@ static int density_step(ghip_ctx *ctx)
           K.boxsize = D.dp.BoxSize;
           K.boxhalf = 0.5 * D.dp.BoxSize;
           K.periodic = D.dp.periodic;
-          K.margin = D.gh_margin;
+          K.margin = D.gh_margin_cur;
           K.nranks = P_;
           K.me = D.rank;
           // the local gas particles in the gravity tree's order (chunks of 64 are compact)
@@ -1152,24 +1192,70 @@ static int density_step(ghip_ctx *ctx)
       // gas tree over the local gas and the ghosts, the h iteration for the local targets
       D.nghost = D.x.rtotal;
       GCHK(ghip_dd_build_gas_tree(ctx));
-      GCHK(ghip_density_impl(ctx, &D.dp));
-      // every search radius used must have stayed inside the padded radius the ghosts were
-      // selected with
-      if(ctx->nt_gas > 0)
+      D.dens_rc = ghip_density_impl(ctx, &D.dp);
+      if(D.dens_rc != GHIP_OK)
+        D.dens_msg = ctx->err;
+      // Every search radius used must have stayed inside the padded radius the ghosts were selected
+      // with.  The reference re-exports a target at every h iteration, whatever its radius has become
+      // (density.c:160-677); here the ghosts are fixed for the call, so a radius that outgrows the
+      // padding -- the first density() of a run grows a poor guess by 1.26 per pass -- means: select the
+      // ghosts again with a larger padding and repeat the call from the smoothing lengths it started
+      // with.  The decision is taken by ALL shards on the all-gathered growth factors, so that they
+      // repeat (or fail) together; a rank-local failure of the iteration travels the same way.
+      double mine[2] = {0.0, 0.0};
+      if(D.dens_rc == GHIP_OK && ctx->nt_gas > 0)
         {
           unsigned long long *dr = P<unsigned long long>(ctx->counters) + 34;
           HIPCHK(hipMemsetAsync(dr, 0, 8, st));
           k_ghost_growth<<<cdiv(ctx->nt_gas, 256), 256, 0, st>>>(
             ctx->nt_gas, P<int>(ctx->tg_gas), P<int>(ctx->st.perm), P<double>(ctx->dhcur),
             P<double>(ctx->dright), P<double>(D.h0), dr);
-          double ratio = 0;
-          HIPCHK(hipMemcpyAsync(&ratio, dr, 8, hipMemcpyDeviceToHost, st));
+          HIPCHK(hipMemcpyAsync(&mine[0], dr, 8, hipMemcpyDeviceToHost, st));
           HIPCHK(ghip_stream_sync(ctx, st));
-          D.gh_growth = ratio;
-          if(ratio > D.gh_margin)
-            return ghip_fail(ctx, GHIP_EDEVICE,
-                             "density: a smoothing length grew by %.3f in this call, more than the "
-                             "ghost margin %.3f (ghip_dd_set_ghost_margin)", ratio, D.gh_margin);
+        }
+      mine[1] = D.dens_rc != GHIP_OK ? 1.0 : 0.0;
+      D.gh_growth = mine[0];
+      GCHK(ghip_ensure(ctx, D.status_own, 16));
+      HIPCHK(hipMemcpyAsync(D.status_own.p, mine, 16, hipMemcpyHostToDevice, st));
+      HIPCHK(ghip_stream_sync(ctx, st));
+      set_allgather(D, D.status_own.p, 16, &D.status_all);
+      D.phase = 25;
+      return 1;
+    }
+  if(D.phase == 25)
+    {
+      double all[2 * GHIP_MAXRANKS];
+      HIPCHK(hipMemcpyAsync(all, D.status_all.p, (size_t) P_ * 16, hipMemcpyDeviceToHost, st));
+      HIPCHK(ghip_stream_sync(ctx, st));
+      double worst = 0;
+      int failed = -1;
+      for(int r = 0; r < P_; r++)
+        {
+          if(all[2 * r] > worst)
+            worst = all[2 * r];
+          if(all[2 * r + 1] != 0 && failed < 0)
+            failed = r;
+        }
+      if(worst > D.gh_margin_cur && P_ > 1)
+        {
+          // (a failed iteration of the incomplete attempt -- non-convergence next to missing ghosts --
+          // is repeated like everything else)
+          if(D.gh_retries >= 40)
+            return ghip_fail(ctx, GHIP_ENOCONV, "density: the ghost radius grew %d times without covering "
+                             "the smoothing lengths (largest growth %.3g)", D.gh_retries, worst);
+          D.gh_retries++;
+          D.gh_margin_cur = 1.26 * worst;   // one more pass of the reference's growth factor as head-room
+          if(ng > 0)
+            HIPCHK(hipMemcpyAsync(ctx->f[GHIP_F_HSML].p, D.h0.p, (size_t) ng * 8, hipMemcpyDeviceToDevice, st));
+          D.phase = 0;
+          return density_step(ctx);   // groups with the larger padding -> all-gather -> ...
+        }
+      if(failed >= 0)
+        {
+          if(D.dens_rc != GHIP_OK)
+            return ghip_fail(ctx, D.dens_rc, "%s", D.dens_msg.c_str());
+          return ghip_fail(ctx, GHIP_EDEVICE, "density: the h iteration failed on shard %d (its own message "
+                           "says why); every shard stops here", failed);
         }
       // the ghosts' records as they are after density(): hydro_force needs h, rho, P, f, div, curl
       GCHK(pack_ghosts(ctx, D.gh_sent));
@@ -1497,7 +1583,12 @@ extern "C" int ghip_dd_begin(ghip_ctx *ctx, int op, const void *params, int walk
       D.walk = walk;
     }
   else if(op == DD_OP_DENSITY)
-    D.dp = *reinterpret_cast<const ghip_dens_params *>(params);
+    {
+      D.dp = *reinterpret_cast<const ghip_dens_params *>(params);
+      D.gh_margin_cur = D.gh_margin;   // (grows within the call when a smoothing length outgrows it)
+      D.gh_retries = 0;
+      D.dens_rc = GHIP_OK;
+    }
   else if(op == DD_OP_HYDRO)
     D.hp = *reinterpret_cast<const ghip_hydro_params *>(params);
   else if(op >= GHIP_DD_SINK_DENSITY && op <= GHIP_DD_BH_SWALLOW)
@@ -1605,7 +1696,7 @@ void ghip_dd_release(ghip_ctx *ctx)
     return;
   ghip_dd_comm_release(ctx);
   DDState &D = ctx->dd;
-  DevBuf *bs[] = {&D.xstage, &D.grp_own, &D.grp_all, &D.reach, &D.sendm, &D.selcnt, &D.let_list,
+  DevBuf *bs[] = {&D.status_own, &D.status_all, &D.xstage, &D.grp_own, &D.grp_all, &D.reach, &D.sendm, &D.selcnt, &D.let_list,
                   &D.let_send, &D.let_recv, &D.src_x, &D.src_y, &D.src_z, &D.src_m, &D.src_aux,
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
                   &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,

@@ -94,6 +94,11 @@ struct TreeDev
 #define DD_NSUB 16
 #define DD_NGROUPS (DD_NSUPER * DD_NSUB)
 #define DD_TABLE (DD_NSUPER + DD_NGROUPS)   // records per shard: super-groups first
+// ... and one status record behind them (cx != 0: this shard met an error while it prepared the
+// table -- a particle outside its key range, a device invariant): every shard reads every status after
+// the all-gather and all of them fail TOGETHER, instead of one returning while its peers wait for it
+// inside the next collective
+#define DD_STRIDE (DD_TABLE + 1)
 struct __attribute__((aligned(64))) DDGroup
 {
   double cx, cy, cz;   // box centre
@@ -173,6 +178,13 @@ struct DDState
   DevBuf gh_send, gh_recv;        // GhostRec[]
   int nghost = 0;
   double gh_margin = 1.3;         // search radii are padded by this factor when ghosts are selected
+  double gh_margin_cur = 1.3;     // ... in the density call in progress: grows when an h outgrew it (see density_step)
+  int gh_retries = 0;             // re-selections of the density call in progress
+  DevBuf status_own, status_all;  // f64[2] per shard: {largest Hsml growth, error flag} of a density call
+  int local_err = 0;              // what this shard itself met while it prepared its group table
+  std::string local_msg;
+  int dens_rc = 0;                // ... and in the h iteration of the density call in progress
+  std::string dens_msg;
   DevBuf gh_ratio;                // f64[2]: largest Hsml growth seen by the density iterations
   DevBuf gsx, gsy, gsz, gsm, gsh; // gas sources = local gas + ghosts (tree build input)
   DevBuf h0;                      // f64[ngas]: smoothing lengths the ghost selection was made with

@@ -64,7 +64,6 @@ def test_sharded_density_and_hydro_equal_the_single_rank_sums(nshards, periodic)
     pr = Problem(ng=12, gas=True, periodic=periodic)
     S = ShardSet(pr, nshards)
     try:
-        S.each(lambda fp: fp.dd_set_ghost_margin(2.0))    # the first guess of h is poor (common.py)
         S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)  # the tree of this step
         S.run.density(pr.g_dens())
         S.each(lambda fp: fp.update_hmax())
@@ -95,6 +94,50 @@ def test_sharded_density_and_hydro_equal_the_single_rank_sums(nshards, periodic)
         S.close()
 
 
+@pytest.mark.parametrize("nshards", [3, 8])
+def test_smoothing_lengths_that_triple_in_one_call_reselect_their_ghosts(nshards):
+    """The first density() of a run starts from a poor guess and grows h by 1.26 per pass
+    (density.c:610-642; init.c:740-741): here every smoothing length starts at a quarter of the usual
+    first guess and must grow two- to more than threefold within ONE call.  The reference re-exports a target at every
+    iteration; the shards select their ghosts once per call with the default padding (1.3), notice
+    -- all of them together, on the all-gathered growth factors -- that the search radii outgrew it,
+    select again with the radius that was needed and repeat the call from the smoothing lengths it
+    started with.  Result: the single global tree's, iteration and neighbour-visit counts of the
+    repeated attempt included."""
+    B = bindings()
+    pr = Problem(ng=12, gas=True, periodic=1)
+    ng = pr.ngas
+    h_start = pr.hsml0.copy()
+    h_start[:ng] = pr.hsml0[:ng] / 4.0
+    S = ShardSet(pr, nshards)
+    try:
+        S.set_field(B.F_HSML, h_start)
+        S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)  # the tree of this step
+        S.run.density(pr.g_dens())
+        S.each(lambda fp: fp.update_hmax())
+        S.run.hydro(pr.g_hydro())
+        T = O.Tree(pr.ic["pos"], pr.ic["vel"], pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=h_start,
+                   extent=pr.extent)
+        act = np.arange(ng, dtype=np.int32)
+        od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                       pr.ti_begstep, h_start)
+        growth = od["hsml"][:ng] / h_start[:ng]
+        assert growth.min() > 1.9 and growth.max() > 3.0                 # they double to more than triple
+        T.update_hmax(act, od["hsml"], od["divvel"])
+        oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
+                     od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
+        for fid, key in ((B.F_HSML, "hsml"), (B.F_NUMNGB, "numngb"), (B.F_DENSITY, "density")):
+            assert relerr(S.get_field(fid)[:ng], od[key][:ng]) < 1e-9, key
+        st = S.each(lambda fp: fp.stats())
+        assert sum(s["dens_neighbours"] for s in st) == od["ngb_visits"]
+        assert max(s["dens_iterations"] for s in st) == od["iterations"]
+        assert sum(s["hydro_pairs"] for s in st) == oh["npairs"]
+        info = S.each(lambda fp: fp.dd_info())
+        assert max(i["hsml_growth_e6"] for i in info) > 2.0e6      # beyond the default padding of 1.3
+    finally:
+        S.close()
+
+
 def test_config_c4_128cubed_as_eight_logical_shards():
     """c4 (128^3 DM + 128^3 gas, Peano-Hilbert domain decomposition over 8 GPUs): the whole workload
     as 8 logical shards run one after the other on one GPU, tree nodes and ghosts handed across in
@@ -112,7 +155,6 @@ def test_config_c4_128cubed_as_eight_logical_shards():
         sizes = [len(g) for g in S.gid]
         assert sum(sizes) == n and max(sizes) < 1.3 * n / 8
         S.run.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
-        S.each(lambda fp: fp.dd_set_ghost_margin(1.6))
         S.run.density(pr.g_dens())
         S.each(lambda fp: fp.update_hmax())
         S.run.hydro(pr.g_hydro())
@@ -168,7 +210,6 @@ def test_config_c5_256cubed_with_sinks_as_eight_logical_shards():
         sizes = [len(g) for g in S.gid]
         assert sum(sizes) == n and max(sizes) < 1.3 * n / 8
         S.run.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
-        S.each(lambda fp: fp.dd_set_ghost_margin(1.6))
         S.run.density(pr.g_dens())
         S.each(lambda fp: fp.update_hmax())
         S.run.hydro(pr.g_hydro())
@@ -404,7 +445,6 @@ def test_sharded_sph_variants(variant):
     ng = pr.ngas
     S = ShardSet(pr, nsh)
     try:
-        S.each(lambda fp: fp.dd_set_ghost_margin(3.0))
         act = np.arange(ng, dtype=np.int32)
         S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
         if variant == "subset":

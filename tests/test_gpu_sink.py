@@ -95,7 +95,6 @@ def test_sink_passes_on_shards(nshards, periodic, dust_only, acc_density):
                    hsml=sp.hsml, extent=pr.extent)
         od = O.sink_density(T, pr.o_dens(), 1.5, sp.sinks, pr.velpred, pr.entropy, sp.hsml)
         # the trees of this step
-        S.each(lambda fp: fp.dd_set_ghost_margin(2.0))
         S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
         S.run.density(pr.g_dens())
         gd = pr.g_dens()
