@@ -132,6 +132,10 @@ def main():
     n_total, ngas_total = pr.n, pr.ngas
     tl = Timeline(B, pr)
     pr.timebase = tl.tb
+    # The domain cube (DomainCorner / DomainCenter / DomainLen).  The reference recomputes the particles'
+    # extent at every decomposition (domain.c:1972-2014); a resident loop keeps one cube for the run, and
+    # in a periodic box that cube is the box -- every wrapped position lies inside it, whatever drifts.
+    pr.extent = (np.zeros(3), np.full(3, 0.5 * pr.box), pr.box)
     tree_args = (pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
     gp_bh, gp_rel = pr.g_grav(pr.theta), pr.g_grav(0.0)
     hp = pr.g_hydro()
@@ -407,6 +411,8 @@ def main():
         try:
             out["dropin_ms_per_step"] = dropin_timing(pr)
             out["dropin_ms_per_step"]["with_overlap_sph"] = dropin_timing(pr, overlap_sph=1)
+            out["dropin_ms_per_step"]["with_overlap_sph_and_pin_records"] = dropin_timing(
+                pr, overlap_sph=1, pin_records=1)
         except Exception as e:
             out["dropin_ms_per_step"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -507,7 +513,7 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
     return r
 
 
-def dropin_timing(pr_bench, reps=3, overlap_sph=0):
+def dropin_timing(pr_bench, reps=3, overlap_sph=0, pin_records=0):
     """The PCIe-inclusive drop-in path accel.c would see: gravity_tree(), density(),
     force_update_hmax(), hydro_force() of libgadget_force.so on AoS P[]/SphP[] records, each with its
     H2D / D2H of the record blocks (SURVEY 8d's metric "including host<->device packing").  Never part
@@ -516,7 +522,7 @@ def dropin_timing(pr_bench, reps=3, overlap_sph=0):
     from test_gpu_parity import _host_problem
     H = importlib.import_module("gadget-leicester_amd.hostapi")
     pr = Problem(ng=round((pr_bench.n // 2) ** (1 / 3)), gas=True, periodic=1)
-    host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap_sph)
+    host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap_sph, pin_records=pin_records)
     L = host.L
     L.gravity_tree()                             # Barnes-Hut pass for OldAcc
     L.gadget_force_flush()
@@ -535,12 +541,14 @@ def dropin_timing(pr_bench, reps=3, overlap_sph=0):
     return {"total": sum(best), "gravity_tree": best[0], "density": best[1],
             "force_update_hmax": best[2], "hydro_force": best[3], "ok": ok,
             "particle_steps_per_s": pr.n / (1e-3 * sum(best)),
-            "overlap_sph": overlap_sph,
+            "overlap_sph": overlap_sph, "pin_records": pin_records,
             "note": "host calls the four drivers one after the other on 112-B / 184-B records; "
                     "each uploads / downloads the record blocks over PCIe"
                     + ("; gadget_force_config.overlap_sph: the gravity walks stay in flight underneath "
                        "density / hydro_force and their results arrive with hydro_force()"
-                       if overlap_sph else "")}
+                       if overlap_sph else "")
+                    + ("; gadget_force_config.pin_records: P[] / SphP[] page-locked once"
+                       if pin_records else "")}
 
 
 def kick_roofline(pr, fp, B, reps=5):

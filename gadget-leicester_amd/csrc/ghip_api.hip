@@ -141,7 +141,8 @@ int ghip_check_device_errors(ghip_ctx *ctx)
     "the wavefront plan of a gravity walk exceeded its grid (ghip_walk.h, k_plan_fill)",
     "a target had to open a pruned node of an imported (other shard's) tree: the locally "
     "essential tree was incomplete",
-    "tree emission outside the element list or a malformed imported element",
+    "tree emission outside the element list, a malformed imported element (3), a particle outside its "
+    "shard's key range (5: migrate first) or outside the domain cube (6: ghip_dd_set_domain with a fresh extent)",
     "ghost import", "drift", "timestep", "", ""};
   for(int w = 0; w < GHIP_ERRW_COUNT; w++)
     {
@@ -321,6 +322,9 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   free_buf(ctx->pm_force);
   if(ctx->pinned)
     (void) hipHostFree(ctx->pinned);
+  for(void *p : ctx->host_pins)
+    (void) hipHostUnregister(p);
+  ctx->host_pins.clear();
   if(ctx->ev_ready)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
@@ -769,6 +773,44 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
   HIPCHK(ghip_stream_sync(ctx, st));
   return ghip_check_device_errors(ctx);
+}
+
+extern "C" int ghip_pin_host(ghip_ctx *ctx, void *ptr, size_t bytes)
+{
+  if(!ctx || !ptr || bytes == 0)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_pin_host: bad arguments");
+  (void) hipSetDevice(ctx->device);
+  for(void *p : ctx->host_pins)
+    if(p == ptr)
+      return ghip_fail(ctx, GHIP_EINVAL, "ghip_pin_host: this array is already locked (ghip_unpin_host first)");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if(e != hipSuccess)
+    {
+      (void) hipGetLastError();   // not an error of the path: the copies stay staged
+      ctx->err = std::string("ghip_pin_host: the range could not be page-locked (") + hipGetErrorString(e) +
+                 "); record copies go through the runtime's staging buffers";
+      return GHIP_OK;
+    }
+  ctx->host_pins.push_back(ptr);
+  return GHIP_OK;
+}
+
+extern "C" int ghip_unpin_host(ghip_ctx *ctx, void *ptr)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  for(size_t i = 0; i < ctx->host_pins.size(); i++)
+    if(ctx->host_pins[i] == ptr)
+      {
+        // a copy in flight may still read the range
+        GHIP_JOIN(ctx);
+        (void) ghip_stream_sync(ctx, ctx->stream);
+        (void) hipHostUnregister(ptr);
+        (void) hipGetLastError();
+        ctx->host_pins.erase(ctx->host_pins.begin() + (long) i);
+        return GHIP_OK;
+      }
+  return GHIP_OK;   // never locked (or the lock had failed): nothing to do
 }
 
 __global__ void k_pack_i16(size_t n, char *__restrict__ rec, int stride, int off,

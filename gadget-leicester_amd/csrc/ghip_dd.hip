@@ -163,7 +163,7 @@ __global__ void k_dd_ph_keys(int n, const double *__restrict__ x, const double *
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  key[i] = d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac), (int) ((z[i] - cz) * fac));
+  key[i] = d_peano21(d_cell21(x[i], cx, fac), d_cell21(y[i], cy, fac), d_cell21(z[i], cz, fac));
 }
 
 extern "C" int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host)
@@ -197,8 +197,9 @@ __global__ void k_dd_check_range(int n, const double *__restrict__ x, const doub
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  unsigned long long k =
-    d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac), (int) ((z[i] - cz) * fac));
+  // (a particle outside the domain cube: error 6, the host must give a fresh extent first)
+  unsigned long long k = d_peano21(d_cell21(x[i], cx, fac, errword), d_cell21(y[i], cy, fac, errword),
+                                   d_cell21(z[i], cz, fac, errword));
   if(k < klo || k >= khi)
     *(volatile int *) errword = 5;
 }
@@ -1324,8 +1325,9 @@ __global__ void k_mig_dest(int n, const double *__restrict__ x, const double *__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  const unsigned long long k =
-    d_peano21((int) ((x[i] - cx) * fac), (int) ((y[i] - cy) * fac), (int) ((z[i] - cz) * fac));
+  // (clamped to the cube: a particle that left it goes to the owner of the boundary cell -- whose range
+  // check then refuses it until the host has set a fresh extent, see d_cell21)
+  const unsigned long long k = d_peano21(d_cell21(x[i], cx, fac), d_cell21(y[i], cy, fac), d_cell21(z[i], cz, fac));
   int lo = 0, hi = S.nranks - 1;   // largest r with s[r] <= k
   while(lo < hi)
     {

@@ -341,6 +341,7 @@ struct ghip_ctx
     int walk;
   };
   std::vector<GravCall> grav_log;  // gravity calls since the last tree build
+  std::vector<void *> host_pins;   // ranges page-locked by ghip_pin_host
 
   // ---- run statistics without a host synchronisation per step (ghip_run_begin / ghip_step_begin /
   // ghip_step_end / ghip_get_run_stats): a ring of event sets, device-side accumulated counters ----

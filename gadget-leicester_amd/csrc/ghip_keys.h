@@ -61,6 +61,27 @@ static __device__ __forceinline__ unsigned long long d_peano21(int x, int y, int
   return k;
 }
 
+// Integer coordinate of a position inside the domain cube, (int) ((x - corner) * fac) as the reference
+// forms it (forcetree.c:181-185, domain.c:1090) -- clamped to the cube's 2^21 cells.  A particle of a
+// non-periodic run that has drifted outside the cube handed to ghip_dd_set_domain (or sits exactly on
+// its upper face) would otherwise yield a negative or 22-bit integer and, from it, a garbage key: it
+// could be sent to an arbitrary rank and pass that rank's range check.  Clamped it stays with the rank
+// that owns the boundary cell; *outside (if given) is raised so that the caller can insist on a fresh
+// extent (the reference recomputes it at every decomposition, domain.c:1972-2014).
+static __device__ __forceinline__ int d_cell21(double x, double corner, double fac, int *outside = nullptr)
+{
+  const double c = (x - corner) * fac;
+  int i = (int) c;
+  const int top = (1 << GHIP_BITS) - 1;
+  if(!(c >= 0) || i > top)
+    {
+      if(outside)
+        *(volatile int *) outside = 6;
+      i = !(c >= 0) ? 0 : top;
+    }
+  return i;
+}
+
 // the leading `levels` (<= 10) digits of the same key
 static __device__ __forceinline__ unsigned int d_peano_top(int x, int y, int z, int levels)
 {

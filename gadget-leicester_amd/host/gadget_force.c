@@ -109,6 +109,10 @@ static int Phase = 0;            /* 1 after gravity_tree(), 2 after density(): a
 static int GravPending = 0;      /* overlap_sph: walks in flight, post-pass + download still to do */
 static int GasPending = 0;       /* overlap_sph: P[] is on the device, SphP[] still to follow */
 static int GravPendingActive = 0;
+/* cfg.pin_records: the record arrays page-locked so far */
+static void *PinP, *PinS;
+static size_t PinPBytes, PinSBytes;
+static int DensPending = 0;      /* overlap_sph: density()'s results are still on the device */
 static int *ActiveBuf = NULL;
 static int ActiveCap = 0;
 static int NgblistCap = 0;
@@ -220,7 +224,15 @@ void gadget_force_bind_records(void *host_P, void *host_SphP, const ghip_layout 
 void gadget_force_finalize(void)
 {
   if(Ctx)
-    ghip_destroy(Ctx);
+    {
+      if(PinP)
+        ghip_unpin_host(Ctx, PinP);
+      if(PinS)
+        ghip_unpin_host(Ctx, PinS);
+      ghip_destroy(Ctx);
+    }
+  PinP = PinS = NULL;
+  PinPBytes = PinSBytes = 0;
   Ctx = NULL;
   free(ActiveBuf);
   ActiveBuf = NULL;
@@ -233,6 +245,7 @@ void gadget_force_finalize(void)
   Phase = 0;
   GravPending = 0;
   GasPending = 0;
+  DensPending = 0;
   /* the host's arrays are the host's: forget them, a later init must set them again */
   Nodes_base = Nodes = NULL;
   Extnodes_base = Extnodes = NULL;
@@ -518,10 +531,45 @@ static int need_ctx(const char *who)
   return -1;
 }
 
+static void pin_one(void **have, size_t *have_bytes, void *ptr, size_t bytes)
+{
+  if(*have == ptr && bytes <= *have_bytes)
+    return;
+  if(*have)
+    ghip_unpin_host(Ctx, *have);
+  *have = NULL;
+  *have_bytes = 0;
+  if(!ptr || bytes == 0)
+    return;
+  if(ghip_pin_host(Ctx, ptr, bytes) == 0)
+    {
+      *have = ptr;
+      *have_bytes = bytes;
+    }
+}
+
+static void pin_records(void)
+{
+  if(!Cfg.pin_records || !Ctx)
+    return;
+  /* a little room for a NumPart that creeps up between decompositions, so that not every step
+   * locks again -- never beyond the array the host allocated (All.MaxPart records, allocate.c:38) */
+  size_t np = (size_t) NumPart, ns = (size_t) N_gas;
+  if(PinP != (void *) records_p() || np * (size_t) Lay.p_stride > PinPBytes)
+    {
+      np += np / 16;
+      if(np > (size_t) All.MaxPart)
+        np = (size_t) (All.MaxPart > NumPart ? All.MaxPart : NumPart);
+    }
+  pin_one(&PinP, &PinPBytes, records_p(), np * (size_t) Lay.p_stride);
+  pin_one(&PinS, &PinSBytes, records_s(), ns * (size_t) Lay.s_stride);
+}
+
 /* split != 0 (gravity_tree with overlap_sph): only the P[] block now, the SphP[] block once the walks
  * are in flight (upload_gas_if_pending) */
 static int upload_particles(int split)
 {
+  pin_records();
   if(split && N_gas > 0 && Lay.p_hsml < 0)
     {
       if(chk(ghip_upload_aos_particles(Ctx, records_p(), &Lay, NumPart, N_gas), "ghip_upload_aos_particles"))
@@ -748,6 +796,11 @@ static int gravity_complete(int download)
 
 void gadget_force_flush(void)
 {
+  if(DensPending && Ctx)
+    {
+      DensPending = 0;
+      chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos");
+    }
   if(GravPending && Ctx)
     {
       all_pull();
@@ -949,7 +1002,12 @@ void density(void)
   fill_dens_params(&d);
   if(chk(ghip_density(Ctx, &d), "ghip_density"))
     return;
-  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos"))
+  /* overlap_sph with the walks in flight: nothing reads the density results between density() and
+   * hydro_force() (accel.c:84-106: force_update_hmax is ours), so they travel with the hydro results --
+   * one download of the SphP[] block per step instead of two */
+  if(Cfg.overlap_sph && GravPending)
+    DensPending = 1;
+  else if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos"))
     return;
   if(density_of_sinks(&d))
     return;
@@ -1006,7 +1064,10 @@ void hydro_force(void)
   const int with_gravity = GravPending;
   if(with_gravity && gravity_complete(0))
     return;
-  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, with_gravity, 0, 1), "ghip_download_aos"))
+  const int with_density = DensPending;
+  DensPending = 0;
+  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, with_gravity, with_density, 1),
+         "ghip_download_aos"))
     return;
   Phase = 0;
   CPU_Step_Hydro += wallclock() - t0;

@@ -71,7 +71,7 @@ class Config(C.Structure):
     _fields_ = [("periodic", C.c_int), ("pmgrid", C.c_int), ("unequal_softenings", C.c_int),
                 ("device", C.c_int), ("black_holes", C.c_int), ("dust", C.c_int),
                 ("accretion_of_dust_only", C.c_int), ("accretion_density", C.c_int),
-                ("overlap_sph", C.c_int)]
+                ("overlap_sph", C.c_int), ("pin_records", C.c_int)]
 
 
 class BhLayout(C.Structure):
@@ -193,7 +193,8 @@ class Host:
     and points the library's globals at them."""
 
     def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0, black_holes=0, dust=0,
-                 overlap_sph=0, accretion_of_dust_only=0, accretion_density=0, rank=0, nranks=1):
+                 overlap_sph=0, accretion_of_dust_only=0, accretion_density=0, rank=0, nranks=1,
+                 pin_records=0):
         self.L = lib()
         self.endrun_codes = []
         self._cb = ENDRUN_CB(lambda code: self.endrun_codes.append(code))
@@ -201,7 +202,7 @@ class Host:
         self._seti("ThisTask", rank)
         self._seti("NTask", nranks)
         cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust, accretion_of_dust_only,
-                     accretion_density, overlap_sph)
+                     accretion_density, overlap_sph, pin_records)
         rc = self.L.gadget_force_init(C.byref(cfg))
         if rc != 0:
             raise RuntimeError("gadget_force_init failed (%d): %s" %

@@ -274,11 +274,16 @@ struct gadget_force_config
   int accretion_density;        /* -DACCRETION_DENSITY (blackhole.c:1094) */
   int overlap_sph;         /* 1: on a step with gas, gravity_tree() returns with its walks still in
                               flight and density() / force_update_hmax() / hydro_force() run underneath
-                              them on the device; the gravity results (GravAccel, OldAcc, GravCost)
-                              reach P[] when hydro_force() returns -- or gadget_force_flush().  Valid
+                              them on the device; the gravity results (GravAccel, OldAcc, GravCost) and
+                              density()'s (one download of the SphP[] block per step instead of two)
+                              reach the records when hydro_force() returns -- or gadget_force_flush().  Valid
                               for accel.c's sequence (accel.c:61-106: nothing reads P[].g.GravAccel
                               between the four calls); 0 (default): every driver returns with its own
                               results in P[] / SphP[] */
+  int pin_records;         /* 1: page-lock the first NumPart / N_gas records of P[] / SphP[] when they
+                              are first uploaded (again when the arrays move or grow), so the record
+                              copies run at the link's rate; released by gadget_force_finalize().  The
+                              reference allocates both arrays once for All.MaxPart (allocate.c:30-60) */
 };
 
 /* ---- globals with the reference's names (allvars.c) ---- */

@@ -261,6 +261,13 @@ int ghip_upload_aos_particles(ghip_ctx *ctx, const void *P, const ghip_layout *l
 int ghip_upload_aos_gas(ghip_ctx *ctx, const void *SphP, const ghip_layout *lay);
 int ghip_download_aos(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay,
                       int want_gravity, int want_density, int want_hydro);
+/* Page-lock a host array the record copies go through (the reference allocates P[] / SphP[] once
+ * for All.MaxPart, allocate.c:30-60): the copies then run at the link's rate instead of through
+ * the runtime's staging buffers.  Optional; a range that cannot be locked is left as it is
+ * (returns GHIP_OK, ghip_last_error tells).  ghip_unpin_host before the array is freed;
+ * ghip_destroy releases what is left. */
+int ghip_pin_host(ghip_ctx *ctx, void *ptr, size_t bytes);
+int ghip_unpin_host(ghip_ctx *ctx, void *ptr);
 
 /* ---- active list (FirstActiveParticle/NextActiveParticle, run.c:300-320) ---- */
 /* host indices of the active particles; NULL or n == numpart with idx NULL: all active */
@@ -320,8 +327,10 @@ int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host);
 /* domain_findSplit_work_balanced (domain.c:1075-1113, equal speed factors): cut ndomain
  * curve-ordered pieces of work into ncpu contiguous ranges [start[i], end[i]].  Host arithmetic. */
 int ghip_dd_find_split(int ncpu, int ndomain, const double *domainWork, int *start, int *end);
-/* search radii are padded by this factor when ghosts are selected (default 1.3); a density() whose
- * h iteration leaves the padded radius fails with GHIP_EDEVICE */
+/* search radii are padded by this factor when ghosts are first selected in a density() (default
+ * 1.3).  Only a performance knob: when the h iteration takes a smoothing length beyond the padded
+ * radius on any shard, all shards restore their starting Hsml, select ghosts again with
+ * 1.26 x the worst growth seen and repeat the iteration (a collective decision). */
 int ghip_dd_set_ghost_margin(ghip_ctx *ctx, double margin);
 /* RCCL: rank 0 creates the id (128 bytes) and the host broadcasts it (MPI_Bcast in the reference's
  * world); every rank then connects.  The library binds the librccl that sits next to the HIP

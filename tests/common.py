@@ -131,6 +131,36 @@ class Problem:
         fp.tree_build(self.extent[0], self.extent[1], self.extent[2], self.force_soft)
 
 
+def sampled_hydro_check(pr, T, get_field, act, tol=1e-11, hparams=None):
+    """hydro_force() of a big configuration against the oracle on the gas targets `act`: the oracle's
+    hydro_evaluate for those targets on the DEVICE's density results of all gas particles (smoothing
+    lengths, densities, pressures, f, div v, curl v -- themselves checked against the oracle's
+    density() on the sample), after force_update_hmax() with the same values.  Checks HydroAccel,
+    DtEntropy and MaxSignalVel of the sample; returns the oracle's pair count for them."""
+    B = bindings()
+    n, ng = pr.n, pr.ngas
+
+    def gas(field):
+        a = np.zeros(n)
+        a[:ng] = get_field(field)[:ng]
+        return a
+    hs = np.asarray(get_field(B.F_HSML), np.float64).copy()
+    dens, pres, dhf = gas(B.F_DENSITY), gas(B.F_PRESSURE), gas(B.F_DHSMLFAC)
+    divv, curl = gas(B.F_DIVVEL), gas(B.F_CURLVEL)
+    allgas = np.arange(ng, dtype=np.int32)
+    T.update_hmax(allgas, hs, divv)
+    oh = T.hydro(hparams if hparams is not None else pr.o_hydro(), act, pr.velpred, hs, dens, pres, dhf,
+                 divv, curl, pr.timebin)
+    ha = get_field(B.F_HYDROACCEL)
+    scale = np.abs(oh["hydroaccel"][act]).max()
+    assert np.abs(ha[act] - oh["hydroaccel"][act]).max() < tol * scale, "HydroAccel of the sample"
+    de = get_field(B.F_DTENTROPY)
+    assert np.abs(de[act] - oh["dtentropy"][act]).max() < tol * max(np.abs(oh["dtentropy"][act]).max(), 1e-300)
+    ms = get_field(B.F_MAXSIGNALVEL)
+    assert relerr(ms[act], oh["maxsignalvel"][act]) < tol, "MaxSignalVel of the sample"
+    return oh["npairs"]
+
+
 def relerr(a, b):
     """max_i |a_i - b_i| / |b_i| over vectors (rows)."""
     a = np.asarray(a, dtype=np.float64)

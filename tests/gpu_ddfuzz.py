@@ -70,7 +70,6 @@ def one(seed):
         assert np.abs(S.get_field(B.F_GRAVACCEL) - oacc).max() < 1e-10 * scale, "gravity"
         sph = ng >= 40
         if sph:
-            S.each(lambda fp: fp.dd_set_ghost_margin(3.0))
             act = np.arange(ng, dtype=np.int32)
             S.run.density(pr.g_dens())
             od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,

@@ -51,12 +51,10 @@ def main():
             work = 1.0 + S0.get_field(B.F_GRAVCOST).astype(np.float64)
             S0.close()
         S = ShardSet(pr, P, work=work)
-        S.each(lambda fp: fp.dd_set_ghost_margin(2.0))
         # step 0: Barnes-Hut pass for OldAcc, density to converge h; then the measured step
         run_op(S, B.DD_GRAVITY, pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
         S.each(lambda fp: fp.gravity_finish(pr.G))
         run_op(S, B.DD_DENSITY, pr.g_dens())
-        S.each(lambda fp: fp.dd_set_ghost_margin(1.3))
         for rep in range(2):
             mig = run_op(S, B.DD_MIGRATE, None)
             g = run_op(S, B.DD_GRAVITY, pr.g_grav(0.0), B.WALK_NEWTON_EWALD)

@@ -8,7 +8,7 @@ counts must be exact and the sums agree to summation order."""
 import numpy as np
 import pytest
 
-from common import O, Problem, ShardSet, SinkProblem, bindings, relerr
+from common import O, Problem, ShardSet, SinkProblem, bindings, relerr, sampled_hydro_check
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -181,6 +181,8 @@ def test_config_c4_128cubed_as_eight_logical_shards():
         ha = S.get_field(B.F_HYDROACCEL)
         mg = pr.ic["mass"][:ng]
         assert np.abs((mg[:, None] * ha).sum(axis=0)).max() < 1e-10 * np.abs(mg[:, None] * ha).sum()
+        # hydro_force of the sampled targets (from all shards) against the oracle's hydro_evaluate
+        assert sampled_hydro_check(pr, T, S.get_field, act) > 20 * len(act)
         for r, i in enumerate(info):
             print("shard %d: %d particles, %d tree elements imported (%.1f MB sent), %d ghosts "
                   "imported (%.1f MB sent), merged tree %d elements" %
@@ -230,6 +232,13 @@ def test_config_c5_256cubed_with_sinks_as_eight_logical_shards():
         T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
         assert np.array_equal(cost[sample], ocost)
         assert relerr(acc[sample], oacc) < TOL
+        # density() and hydro_force() of sampled gas targets from all shards against the oracle
+        act = sample[sample < ng][:128]
+        od0 = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                        pr.hsml0)
+        assert relerr(S.get_field(B.F_DENSITY)[act], od0["density"][act]) < TOL
+        assert relerr(S.get_field(B.F_HSML)[act], od0["hsml"][act]) < TOL
+        assert sampled_hydro_check(pr, T, S.get_field, act) > 20 * len(act)
         # ---- the sinks, spread over the shards ----
         where = S.locate(sp.sinks)
         assert sum(len(w[0]) for w in where) == 300 and sum(len(w[0]) > 0 for w in where) >= 4
@@ -288,6 +297,31 @@ def test_config_c5_256cubed_with_sinks_as_eight_logical_shards():
         S.close()
 
 
+def test_a_particle_outside_the_domain_cube_is_refused_by_every_shard():
+    """A non-periodic run whose particle has drifted out of the cube given to ghip_dd_set_domain (the
+    reference recomputes the extent at every decomposition, domain.c:1972-2014): its integer
+    coordinates are clamped to the cube, so the migration sends it to the owner of the boundary cell
+    instead of to wherever a garbage key points -- nobody is lost -- and the next force computation is
+    refused by ALL shards together (the status record behind the group tables), the shard that holds
+    the particle saying why."""
+    B = bindings()
+    pr = Problem(ng=8, gas=True, periodic=0)
+    n = pr.n
+    S = ShardSet(pr, 3)
+    try:
+        pos = pr.ic["pos"].copy()
+        far = int(np.argmax(pos[:, 0]))
+        pos[far, 0] = pr.extent[0][0] + 1.2 * pr.extent[2]     # 20 % of the cube's length beyond its face
+        S.set_field(B.F_POS, pos)
+        S.migrate()
+        assert np.array_equal(np.sort(np.concatenate(S.gid)), np.arange(n))   # nobody lost, nobody doubled
+        with pytest.raises(B.GhipError) as e:
+            S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON)
+        assert "domain cube" in str(e.value) or "reported an error" in str(e.value)
+    finally:
+        S.close()
+
+
 def test_migration_moves_every_field_with_its_particle():
     """GHIP_DD_MIGRATE (domain_exchange, domain.c:665-1060): after the particles have moved, every
     one lies in the key range of the shard that holds it, every resident field has followed its
@@ -310,6 +344,10 @@ def test_migration_moves_every_field_with_its_particle():
         newpos = np.mod(pr.ic["pos"] + 0.08 * rng.standard_normal((n, 3)), 1.0)
         newpos[newpos >= 1.0] = 0.0
         S.set_field(B.F_POS, newpos)
+        # positions changed: a fresh extent, as domain_Decomposition takes one (domain.c:1972-2014) --
+        # a particle outside the cube of the old one would be refused
+        ext2 = O.domain_extent(newpos)
+        S.each(lambda fp: fp.dd_set_domain(ext2[0], ext2[1], ext2[2], pr.force_soft))
         before = S.owner.copy()
         S.migrate()
         moved = int((S.owner != before).sum())
@@ -330,7 +368,7 @@ def test_migration_moves_every_field_with_its_particle():
         # and the path runs on the re-sharded set
         pr2 = Problem(ng=10, gas=True, periodic=1)
         pr2.ic["pos"] = newpos
-        pr2.extent = pr.extent
+        pr2.extent = ext2
         T = pr2.oracle_tree()
         tg = np.arange(n, dtype=np.int32)
         S.set_field(B.F_OLDACC, np.zeros(n))

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from common import O, Problem, bindings, ics, relerr
+from common import O, Problem, bindings, ics, relerr, sampled_hydro_check
 
 pytestmark = pytest.mark.gpu
 
@@ -696,12 +696,13 @@ def test_overlap_sph_sequence_gives_the_same_records():
     force_update_hmax() / hydro_force() run underneath, the gravity results arrive with
     hydro_force().  The records after accel.c's sequence equal those of the plain sequence bit for
     bit (same kernels, same launch shapes), and gadget_force_flush() completes a gravity_tree() that
-    no hydro_force() follows."""
+    no hydro_force() follows.  The overlapping host also page-locks its record arrays
+    (pin_records), which changes how the blocks travel and nothing else."""
     H = importlib.import_module("gadget-leicester_amd.hostapi")
     pr = Problem(ng=12, gas=True, periodic=1)
     res = []
     for overlap in (0, 1):
-        host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap)
+        host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap, pin_records=overlap)
         L = host.L
         L.gravity_tree()
         L.gravity_tree()                 # accel.c:63-64: completes the first pass before it starts
@@ -1723,6 +1724,8 @@ def test_config_c3_128cubed_shortrange_tree_and_sph_sampled():
     assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
     assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
     assert np.abs(nn[act] - od["numngb"][act]).max() < 1e-10    # kernel-weighted count (density.c:876)
+    # hydro_force of the sample against the oracle's hydro_evaluate (hydra.c:822) on the same state
+    assert sampled_hydro_check(pr, T, fp.get_field, act) > 20 * len(act)
 
 
 def test_config_c5_size_256cubed_one_step_sampled():
@@ -1762,6 +1765,13 @@ def test_config_c5_size_256cubed_one_step_sampled():
     T.gravity_ewald_add(pr.o_grav(0.0), O.ewald_table(pr.box), sample, old, oacc, ocost)
     assert np.array_equal(cost[sample], ocost)
     assert relerr(acc[sample], oacc) < TOL
+    # density() and hydro_force() of sampled gas targets against the oracle on the same state
+    act = sample[sample < ng][:128]
+    od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                   pr.hsml0)
+    assert relerr(fp.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
+    assert relerr(fp.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
+    assert sampled_hydro_check(pr, T, fp.get_field, act) > 20 * len(act)
     # ---- the neighbour loops of blackhole.c for the 300 sinks ("next" row N4) on the same state:
     # density of the sinks, marking + feedback, swallowing -- against the oracle on the same tree
     hs = fp.get_field(B.F_HSML)
