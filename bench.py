@@ -409,10 +409,12 @@ def main():
             out["next_rows"] = {"N1_kick": {"error": str(e)}}
     if rank == 0 and world == 1 and not args.no_dropin:
         try:
-            out["dropin_ms_per_step"] = dropin_timing(pr)
-            out["dropin_ms_per_step"]["with_overlap_sph"] = dropin_timing(pr, overlap_sph=1)
+            state = device_state(pr, fp, B, tl)
+            out["dropin_ms_per_step"] = dropin_timing(pr, state)
+            out["dropin_ms_per_step"]["with_overlap_sph"] = dropin_timing(pr, state, overlap_sph=1)
             out["dropin_ms_per_step"]["with_overlap_sph_and_pin_records"] = dropin_timing(
-                pr, overlap_sph=1, pin_records=1)
+                pr, state, overlap_sph=1, pin_records=1)
+            del state
         except Exception as e:
             out["dropin_ms_per_step"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -513,18 +515,37 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
     return r
 
 
-def dropin_timing(pr_bench, reps=3, overlap_sph=0, pin_records=0):
+def device_state(pr, fp, B, tl):
+    """What the timed steps left on the device, as host arrays (for the drop-in leg)."""
+    names = {"pos": B.F_POS, "vel": B.F_VEL, "oldacc": B.F_OLDACC, "hsml": B.F_HSML,
+             "velpred": B.F_VELPRED, "entropy": B.F_ENTROPY, "dtentropy": B.F_DTENTROPY,
+             "timebin": B.F_TIMEBIN, "ti_begstep": B.F_TI_BEGSTEP}
+    st = {k: fp.get_field(f) for k, f in names.items()}
+    st["ti_current"], st["timebase"] = tl.ti, tl.tb
+    return st
+
+
+def dropin_timing(pr_bench, state, reps=3, overlap_sph=0, pin_records=0):
     """The PCIe-inclusive drop-in path accel.c would see: gravity_tree(), density(),
     force_update_hmax(), hydro_force() of libgadget_force.so on AoS P[]/SphP[] records, each with its
-    H2D / D2H of the record blocks (SURVEY 8d's metric "including host<->device packing").  Never part
-    of `value`."""
+    H2D / D2H of the record blocks (SURVEY 8d's metric "including host<->device packing"), on the
+    particle state the timed steps reached (same interaction sets as `value`'s last step).  Never
+    part of `value`."""
     from common import Problem
     from test_gpu_parity import _host_problem
     H = importlib.import_module("gadget-leicester_amd.hostapi")
     pr = Problem(ng=round((pr_bench.n // 2) ** (1 / 3)), gas=True, periodic=1)
     host, P, S = _host_problem(pr, H, 1, overlap_sph=overlap_sph, pin_records=pin_records)
+    ng = pr.ngas
+    P["Pos"], P["Vel"], P["OldAcc"] = state["pos"], state["vel"], state["oldacc"]
+    P["TimeBin"], P["Ti_begstep"] = state["timebin"], state["ti_begstep"]
+    S["VelPred"], S["Entropy"], S["DtEntropy"] = state["velpred"], state["entropy"], state["dtentropy"]
+    S["Hsml"] = state["hsml"][:ng]
+    host.All.Ti_Current, host.All.Timebase_interval = state["ti_current"], state["timebase"]
+    host.domain()
     L = host.L
-    L.gravity_tree()                             # Barnes-Hut pass for OldAcc
+    host.All.ErrTolTheta = 0                     # relative criterion on the run's OldAcc
+    L.gravity_tree()
     L.gadget_force_flush()
     best = None
     for _ in range(reps):
@@ -542,8 +563,8 @@ def dropin_timing(pr_bench, reps=3, overlap_sph=0, pin_records=0):
             "force_update_hmax": best[2], "hydro_force": best[3], "ok": ok,
             "particle_steps_per_s": pr.n / (1e-3 * sum(best)),
             "overlap_sph": overlap_sph, "pin_records": pin_records,
-            "note": "host calls the four drivers one after the other on 112-B / 184-B records; "
-                    "each uploads / downloads the record blocks over PCIe"
+            "note": "host calls the four drivers one after the other on 112-B / 184-B records in the "
+                    "state the timed steps reached; each uploads / downloads the record blocks over PCIe"
                     + ("; gadget_force_config.overlap_sph: the gravity walks stay in flight underneath "
                        "density / hydro_force and their results arrive with hydro_force()"
                        if overlap_sph else "")

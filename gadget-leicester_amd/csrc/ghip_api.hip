@@ -214,7 +214,8 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       }
   ctx->ev_ready = true;
   ctx->evp = ctx->ev;
-  if(hipEventCreateWithFlags(&ctx->ev_sizes, hipEventDisableTiming) != hipSuccess ||
+  if(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming) != hipSuccess ||
+     hipEventCreateWithFlags(&ctx->ev_sizes, hipEventDisableTiming) != hipSuccess ||
      hipEventCreateWithFlags(&ctx->ev_sizes_gas, hipEventDisableTiming) != hipSuccess)
     {
       delete ctx;
@@ -328,6 +329,8 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(ctx->ev_ready)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
+  if(ctx->ev_side)
+    (void) hipEventDestroy(ctx->ev_side);
   if(ctx->ev_sizes)
     (void) hipEventDestroy(ctx->ev_sizes);
   if(ctx->ev_sizes_gas)
@@ -565,6 +568,91 @@ __global__ void k_pack_cost_f32(size_t n, char *__restrict__ rec, int stride, in
     *reinterpret_cast<float *>(rec + i * (size_t) stride + off) = (float) src[i];  // P[].GravCost
 }
 
+// One pass over a record block for all of its fields (instead of one launch per field: every launch
+// re-reads every line of the image).  kind 0: double[ncomp] <-> SoA component arrays of stride n;
+// 1: short <-> int; 2: int <-> int; 3 (pack only): int -> float (P[].GravCost).
+struct RecField
+{
+  void *soa;
+  int off;
+  short ncomp, kind;
+};
+struct RecMap
+{
+  size_t n;
+  int stride, nf;
+  RecField f[16];
+};
+
+static void rec_add(RecMap &m, int off, int ncomp, int kind, void *soa)
+{
+  if(off < 0 || m.nf >= 16)
+    return;
+  m.f[m.nf].soa = soa;
+  m.f[m.nf].off = off;
+  m.f[m.nf].ncomp = (short) ncomp;
+  m.f[m.nf].kind = (short) kind;
+  m.nf++;
+}
+
+// type_off >= 0: the records [0, ngas) are supposed to be gas (allvars.h:1384); *mixed is set when
+// one of them has another Type
+template <bool PACK>
+__global__ void k_records(RecMap m, char *__restrict__ rec, int type_off, int ngas, int *mixed)
+{
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= m.n)
+    return;
+  char *r = rec + i * (size_t) m.stride;
+  for(int k = 0; k < m.nf; k++)
+    {
+      const RecField f = m.f[k];
+      if(f.kind == 0)
+        {
+          double *a = reinterpret_cast<double *>(r + f.off);
+          double *s = reinterpret_cast<double *>(f.soa);
+          for(int c = 0; c < f.ncomp; c++)
+            {
+              if(PACK)
+                a[c] = s[(size_t) c * m.n + i];
+              else
+                s[(size_t) c * m.n + i] = a[c];
+            }
+        }
+      else if(f.kind == 1)
+        {
+          if(PACK)
+            *reinterpret_cast<short *>(r + f.off) = (short) reinterpret_cast<int *>(f.soa)[i];
+          else
+            reinterpret_cast<int *>(f.soa)[i] = (int) *reinterpret_cast<const short *>(r + f.off);
+        }
+      else if(f.kind == 2)
+        {
+          if(PACK)
+            *reinterpret_cast<int *>(r + f.off) = reinterpret_cast<int *>(f.soa)[i];
+          else
+            reinterpret_cast<int *>(f.soa)[i] = *reinterpret_cast<const int *>(r + f.off);
+        }
+      else if(PACK)
+        *reinterpret_cast<float *>(r + f.off) = (float) reinterpret_cast<int *>(f.soa)[i];
+    }
+  if(!PACK && type_off >= 0 && i < (size_t) ngas && *reinterpret_cast<const short *>(r + type_off) != 0)
+    *mixed = 1;
+}
+
+template <bool PACK>
+static int run_records(ghip_ctx *ctx, const RecMap &m, void *img, int type_off = -1,
+                       hipStream_t st = nullptr)
+{
+  if(m.n == 0 || m.nf == 0)
+    return GHIP_OK;
+  const int wg = ghip_wg(ctx);
+  k_records<PACK><<<cdiv((long long) m.n, wg), wg, 0, st ? st : ctx->stream>>>(
+    m, (char *) img, type_off, ctx->ngas, ghip_gas_mixed_word(ctx));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
 #define UNPACK64(cnt, img, stride, off, ncomp, fld)                                           \
   do                                                                                          \
     {                                                                                         \
@@ -592,28 +680,23 @@ static int upload_p_block(ghip_ctx *ctx, const void *Pp, const ghip_layout *lay)
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, ctx->aosP, n * lay->p_stride));
   HIPCHK(hipMemcpyAsync(ctx->aosP.p, Pp, n * lay->p_stride, hipMemcpyHostToDevice, st));
-  const void *ip = ctx->aosP.p;
-  UNPACK64(n, ip, lay->p_stride, lay->p_pos, 3, GHIP_F_POS);
-  UNPACK64(n, ip, lay->p_stride, lay->p_vel, 3, GHIP_F_VEL);
-  UNPACK64(n, ip, lay->p_stride, lay->p_mass, 1, GHIP_F_MASS);
-  UNPACK64(n, ip, lay->p_stride, lay->p_oldacc, 1, GHIP_F_OLDACC);
-  if(lay->p_type >= 0)
-    k_unpack_i16<<<cdiv((long long) n, 256), 256, 0, st>>>(n, (const char *) ip, lay->p_stride,
-                                                           lay->p_type, P<int>(ctx->f[GHIP_F_TYPE]));
-  if(lay->p_timebin >= 0)
-    k_unpack_i16<<<cdiv((long long) n, 256), 256, 0, st>>>(
-      n, (const char *) ip, lay->p_stride, lay->p_timebin, P<int>(ctx->f[GHIP_F_TIMEBIN]));
-  if(lay->p_ti_begstep >= 0)
-    k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
-      n, (const char *) ip, lay->p_stride, lay->p_ti_begstep, P<int>(ctx->f[GHIP_F_TI_BEGSTEP]));
-  if(lay->p_ti_current >= 0)
-    k_unpack_i32<<<cdiv((long long) n, 256), 256, 0, st>>>(
-      n, (const char *) ip, lay->p_stride, lay->p_ti_current, P<int>(ctx->f[GHIP_F_TI_CURRENT]));
-  UNPACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
-  UNPACK64(n, ip, lay->p_stride, lay->p_gravpm, 3, GHIP_F_GRAVPM);
-  if(lay->p_hsml >= 0)
-    UNPACK64(n, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
-  HIPCHK(hipGetLastError());
+  RecMap m;
+  m.n = n;
+  m.stride = lay->p_stride;
+  m.nf = 0;
+  rec_add(m, lay->p_pos, 3, 0, ctx->f[GHIP_F_POS].p);
+  rec_add(m, lay->p_vel, 3, 0, ctx->f[GHIP_F_VEL].p);
+  rec_add(m, lay->p_mass, 1, 0, ctx->f[GHIP_F_MASS].p);
+  rec_add(m, lay->p_oldacc, 1, 0, ctx->f[GHIP_F_OLDACC].p);
+  rec_add(m, lay->p_type, 1, 1, ctx->f[GHIP_F_TYPE].p);
+  rec_add(m, lay->p_timebin, 1, 1, ctx->f[GHIP_F_TIMEBIN].p);
+  rec_add(m, lay->p_ti_begstep, 1, 2, ctx->f[GHIP_F_TI_BEGSTEP].p);
+  rec_add(m, lay->p_ti_current, 1, 2, ctx->f[GHIP_F_TI_CURRENT].p);
+  rec_add(m, lay->p_gravaccel, 3, 0, ctx->f[GHIP_F_GRAVACCEL].p);
+  rec_add(m, lay->p_gravpm, 3, 0, ctx->f[GHIP_F_GRAVPM].p);
+  rec_add(m, lay->p_hsml, 1, 0, ctx->f[GHIP_F_HSML].p);
+  *ghip_gas_mixed_word(ctx) = 0;
+  GCHK(run_records<false>(ctx, m, ctx->aosP.p, lay->p_type));
   return GHIP_OK;
 }
 
@@ -627,20 +710,22 @@ static int upload_s_block(ghip_ctx *ctx, const void *Sp, const ghip_layout *lay)
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, ctx->aosS, ng * lay->s_stride));
   HIPCHK(hipMemcpyAsync(ctx->aosS.p, Sp, ng * lay->s_stride, hipMemcpyHostToDevice, st));
-  const void *is = ctx->aosS.p;
-  if(lay->s_hsml >= 0)
-    UNPACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);  // first ngas entries
-  UNPACK64(ng, is, lay->s_stride, lay->s_velpred, 3, GHIP_F_VELPRED);
-  UNPACK64(ng, is, lay->s_stride, lay->s_entropy, 1, GHIP_F_ENTROPY);
-  UNPACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
-  UNPACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
-  UNPACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
-  UNPACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
-  UNPACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
-  UNPACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
-  UNPACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
-  UNPACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
-  HIPCHK(hipGetLastError());
+  RecMap m;
+  m.n = ng;
+  m.stride = lay->s_stride;
+  m.nf = 0;
+  rec_add(m, lay->s_hsml, 1, 0, ctx->f[GHIP_F_HSML].p);   // first ngas entries
+  rec_add(m, lay->s_velpred, 3, 0, ctx->f[GHIP_F_VELPRED].p);
+  rec_add(m, lay->s_entropy, 1, 0, ctx->f[GHIP_F_ENTROPY].p);
+  rec_add(m, lay->s_dtentropy, 1, 0, ctx->f[GHIP_F_DTENTROPY].p);
+  rec_add(m, lay->s_density, 1, 0, ctx->f[GHIP_F_DENSITY].p);
+  rec_add(m, lay->s_dhsmlfac, 1, 0, ctx->f[GHIP_F_DHSMLFAC].p);
+  rec_add(m, lay->s_divvel, 1, 0, ctx->f[GHIP_F_DIVVEL].p);
+  rec_add(m, lay->s_curlvel, 1, 0, ctx->f[GHIP_F_CURLVEL].p);
+  rec_add(m, lay->s_pressure, 1, 0, ctx->f[GHIP_F_PRESSURE].p);
+  rec_add(m, lay->s_hydroaccel, 3, 0, ctx->f[GHIP_F_HYDROACCEL].p);
+  rec_add(m, lay->s_maxsignalvel, 1, 0, ctx->f[GHIP_F_MAXSIGNALVEL].p);
+  GCHK(run_records<false>(ctx, m, ctx->aosS.p));
   return GHIP_OK;
 }
 
@@ -711,8 +796,8 @@ extern "C" int ghip_upload_aos_gas(ghip_ctx *ctx, const void *Sp, const ghip_lay
   return GHIP_OK;
 }
 
-extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
-                                 int want_gravity, int want_density, int want_hydro)
+static int download_aos_impl(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
+                             int want_gravity, int want_density, int want_hydro, bool sync)
 {
   // the SPH results do not depend on a gravity pair still in flight underneath them
   if(ctx && want_gravity)
@@ -729,50 +814,118 @@ extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_l
   hipStream_t st = ctx->stream;
   void *ip = ctx->aosP.p, *is = ctx->aosS.p;
   bool touchP = false, touchS = false;
+  RecMap mp, mg, ms;   // P fields of all particles, P fields of the gas block, SphP fields
+  mp.n = n, mp.stride = lay->p_stride, mp.nf = 0;
+  mg.n = ng, mg.stride = lay->p_stride, mg.nf = 0;
+  ms.n = ng, ms.stride = lay->s_stride, ms.nf = 0;
   if(want_gravity)
     {
-      PACK64(n, ip, lay->p_stride, lay->p_gravaccel, 3, GHIP_F_GRAVACCEL);
-      PACK64(n, ip, lay->p_stride, lay->p_oldacc, 1, GHIP_F_OLDACC);
-      PACK64(n, ip, lay->p_stride, lay->p_gravpm, 3, GHIP_F_GRAVPM);
-      if(lay->p_gravcost >= 0)
-        k_pack_cost_f32<<<cdiv((long long) n, 256), 256, 0, st>>>(
-          n, (char *) ip, lay->p_stride, lay->p_gravcost, P<int>(ctx->f[GHIP_F_GRAVCOST]));
+      rec_add(mp, lay->p_gravaccel, 3, 0, ctx->f[GHIP_F_GRAVACCEL].p);
+      rec_add(mp, lay->p_oldacc, 1, 0, ctx->f[GHIP_F_OLDACC].p);
+      rec_add(mp, lay->p_gravpm, 3, 0, ctx->f[GHIP_F_GRAVPM].p);
+      rec_add(mp, lay->p_gravcost, 1, 3, ctx->f[GHIP_F_GRAVCOST].p);
       touchP = true;
     }
   if(want_density && ng > 0)
     {
       if(lay->p_hsml >= 0)
         {
-          PACK64(ng, ip, lay->p_stride, lay->p_hsml, 1, GHIP_F_HSML);
-          PACK64(ng, ip, lay->p_stride, lay->p_numngb, 1, GHIP_F_NUMNGB);
+          rec_add(mg, lay->p_hsml, 1, 0, ctx->f[GHIP_F_HSML].p);
+          rec_add(mg, lay->p_numngb, 1, 0, ctx->f[GHIP_F_NUMNGB].p);
           touchP = true;
         }
       else
         {
-          PACK64(ng, is, lay->s_stride, lay->s_hsml, 1, GHIP_F_HSML);
-          PACK64(ng, is, lay->s_stride, lay->s_numngb, 1, GHIP_F_NUMNGB);
+          rec_add(ms, lay->s_hsml, 1, 0, ctx->f[GHIP_F_HSML].p);
+          rec_add(ms, lay->s_numngb, 1, 0, ctx->f[GHIP_F_NUMNGB].p);
         }
-      PACK64(ng, is, lay->s_stride, lay->s_density, 1, GHIP_F_DENSITY);
-      PACK64(ng, is, lay->s_stride, lay->s_dhsmlfac, 1, GHIP_F_DHSMLFAC);
-      PACK64(ng, is, lay->s_stride, lay->s_divvel, 1, GHIP_F_DIVVEL);
-      PACK64(ng, is, lay->s_stride, lay->s_curlvel, 1, GHIP_F_CURLVEL);
-      PACK64(ng, is, lay->s_stride, lay->s_pressure, 1, GHIP_F_PRESSURE);
+      rec_add(ms, lay->s_density, 1, 0, ctx->f[GHIP_F_DENSITY].p);
+      rec_add(ms, lay->s_dhsmlfac, 1, 0, ctx->f[GHIP_F_DHSMLFAC].p);
+      rec_add(ms, lay->s_divvel, 1, 0, ctx->f[GHIP_F_DIVVEL].p);
+      rec_add(ms, lay->s_curlvel, 1, 0, ctx->f[GHIP_F_CURLVEL].p);
+      rec_add(ms, lay->s_pressure, 1, 0, ctx->f[GHIP_F_PRESSURE].p);
       touchS = true;
     }
   if(want_hydro && ng > 0)
     {
-      PACK64(ng, is, lay->s_stride, lay->s_hydroaccel, 3, GHIP_F_HYDROACCEL);
-      PACK64(ng, is, lay->s_stride, lay->s_dtentropy, 1, GHIP_F_DTENTROPY);
-      PACK64(ng, is, lay->s_stride, lay->s_maxsignalvel, 1, GHIP_F_MAXSIGNALVEL);
+      rec_add(ms, lay->s_hydroaccel, 3, 0, ctx->f[GHIP_F_HYDROACCEL].p);
+      rec_add(ms, lay->s_dtentropy, 1, 0, ctx->f[GHIP_F_DTENTROPY].p);
+      rec_add(ms, lay->s_maxsignalvel, 1, 0, ctx->f[GHIP_F_MAXSIGNALVEL].p);
       touchS = true;
     }
+  GCHK(run_records<true>(ctx, mp, ip));
+  GCHK(run_records<true>(ctx, mg, ip));
+  GCHK(run_records<true>(ctx, ms, is));
   HIPCHK(hipGetLastError());
   if(touchP)
     HIPCHK(hipMemcpyAsync(Pp, ip, n * lay->p_stride, hipMemcpyDeviceToHost, st));
   if(touchS)
     HIPCHK(hipMemcpyAsync(Sp, is, ng * lay->s_stride, hipMemcpyDeviceToHost, st));
+  if(!sync)
+    return GHIP_OK;
   HIPCHK(ghip_stream_sync(ctx, st));
   return ghip_check_device_errors(ctx);
+}
+
+extern "C" int ghip_download_aos(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
+                                 int want_gravity, int want_density, int want_hydro)
+{
+  return download_aos_impl(ctx, Pp, Sp, lay, want_gravity, want_density, want_hydro, true);
+}
+
+extern "C" int ghip_download_aos_async(ghip_ctx *ctx, void *Pp, void *Sp, const ghip_layout *lay,
+                                       int want_gravity, int want_density, int want_hydro)
+{
+  return download_aos_impl(ctx, Pp, Sp, lay, want_gravity, want_density, want_hydro, false);
+}
+
+// gravity_tree()'s post-pass and the gravity fields of P[] for a host that called the SPH drivers
+// underneath a pair in flight: ordered after the pair on the pair's own stream, not behind the SPH
+// kernels queued on the main stream -- the P[] block crosses the link while hydro's tail still runs.
+extern "C" int ghip_gravity_to_records(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac,
+                                       void *Pp, const ghip_layout *lay)
+{
+  if(!ctx || !lay)
+    return GHIP_EINVAL;
+  GCHK(ghip_tree_verify(ctx));
+  const size_t n = (size_t) ctx->n;
+  if(n == 0)
+    return GHIP_OK;
+  if(!Pp)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_to_records: null record pointer");
+  if(ctx->aosP.cap < n * lay->p_stride)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_to_records: no device image (call ghip_upload_aos)");
+  const bool side = ctx->grav_pending;
+  hipStream_t st = ctx->stream;
+  if(side)
+    st = ctx->stream2;   // (the pair's last kernel, the Ewald sums' combine, is on this stream)
+  else
+    GHIP_JOIN(ctx);
+  GCHK(ghip_gravity_finish_on(ctx, G, pmgrid, comoving_fac, 0, st));
+  RecMap mp;
+  mp.n = n, mp.stride = lay->p_stride, mp.nf = 0;
+  rec_add(mp, lay->p_gravaccel, 3, 0, ctx->f[GHIP_F_GRAVACCEL].p);
+  rec_add(mp, lay->p_oldacc, 1, 0, ctx->f[GHIP_F_OLDACC].p);
+  rec_add(mp, lay->p_gravpm, 3, 0, ctx->f[GHIP_F_GRAVPM].p);
+  rec_add(mp, lay->p_gravcost, 1, 3, ctx->f[GHIP_F_GRAVCOST].p);
+  GCHK(run_records<true>(ctx, mp, ctx->aosP.p, -1, st));
+  HIPCHK(hipMemcpyAsync(Pp, ctx->aosP.p, n * lay->p_stride, hipMemcpyDeviceToHost, st));
+  if(side)
+    {
+      // whatever the main stream does next comes after the pair and after this
+      HIPCHK(hipEventRecord(ctx->ev_side, st));
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+      ctx->grav_pending = false;
+    }
+  HIPCHK(ghip_stream_sync(ctx, st));
+  return ghip_check_device_errors(ctx);
+}
+
+extern "C" int ghip_gas_block_mixed(ghip_ctx *ctx)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  return *reinterpret_cast<volatile int *>(ghip_gas_mixed_word(ctx)) != 0;
 }
 
 extern "C" int ghip_pin_host(ghip_ctx *ctx, void *ptr, size_t bytes)

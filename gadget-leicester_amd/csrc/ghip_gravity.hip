@@ -833,13 +833,10 @@ extern "C" int ghip_gravity_ext(ghip_ctx *ctx, const ghip_grav_params *p, int wa
 
 // all_shards != 0: every active target regardless of the shard (multi-GPU, replicated mode: after
 // the all-gather of the sharded walks each rank holds all G-less accelerations)
-extern "C" int ghip_gravity_finish_ex(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac,
-                                      int all_shards)
+// the post-pass of gravity_tree() on a given stream (the caller has ordered it after the walks)
+int ghip_gravity_finish_on(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac, int all_shards,
+                           hipStream_t st)
 {
-  if(ctx)
-    GHIP_JOIN(ctx);
-  if(!ctx)
-    return GHIP_EINVAL;
   if(!ctx->gt.built)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_finish: no tree");
   if(pmgrid && !(G != 0))
@@ -850,12 +847,22 @@ extern "C" int ghip_gravity_finish_ex(ghip_ctx *ctx, double G, int pmgrid, doubl
     shard_slice(ctx, ctx->nt_grav, &lo, &nt);
   if(nt == 0)
     return GHIP_OK;
-  k_grav_finish<<<cdiv(nt, 256), 256, 0, ctx->stream>>>(
+  k_grav_finish<<<cdiv(nt, 256), 256, 0, st>>>(
     nt, P<int>(ctx->tg_grav) + lo, P<int>(ctx->gt.perm), ctx->n, G, comoving_fac,
     P<double>(ctx->f[GHIP_F_POS]), pmgrid ? P<double>(ctx->f[GHIP_F_GRAVPM]) : nullptr,
     P<double>(ctx->f[GHIP_F_GRAVACCEL]), P<double>(ctx->f[GHIP_F_OLDACC]));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
+}
+
+extern "C" int ghip_gravity_finish_ex(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac,
+                                      int all_shards)
+{
+  if(ctx)
+    GHIP_JOIN(ctx);
+  if(!ctx)
+    return GHIP_EINVAL;
+  return ghip_gravity_finish_on(ctx, G, pmgrid, comoving_fac, all_shards, ctx->stream);
 }
 
 extern "C" int ghip_gravity_finish(ghip_ctx *ctx, double G)

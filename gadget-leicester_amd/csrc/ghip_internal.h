@@ -342,6 +342,8 @@ struct ghip_ctx
   };
   std::vector<GravCall> grav_log;  // gravity calls since the last tree build
   std::vector<void *> host_pins;   // ranges page-locked by ghip_pin_host
+  bool hydro_early = false;        // ghip_set_hydro_release
+  hipEvent_t ev_side = nullptr;    // end of ghip_gravity_to_records' work on the pair's stream
 
   // ---- run statistics without a host synchronisation per step (ghip_run_begin / ghip_step_begin /
   // ghip_step_end / ghip_get_run_stats): a ring of event sets, device-side accumulated counters ----
@@ -394,6 +396,13 @@ int ghip_join(ghip_ctx *ctx);        // wait for a pair in flight AND complete a
 // one-wavefront workgroups, and a 256-thread workgroup -- which needs four free wavefront slots in
 // one CU at the same moment -- would starve behind them however high its stream's priority.
 static inline int ghip_wg(const ghip_ctx *ctx) { return ctx->grav_pending ? 64 : 256; }
+// pinned word the record unpack sets when a record of the gas block [0, ngas) is not Type 0
+static inline int *ghip_gas_mixed_word(ghip_ctx *ctx)
+{
+  return reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->pinned) + 256);
+}
+int ghip_gravity_finish_on(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac, int all_shards,
+                           hipStream_t st);
 int ghip_join_pair(ghip_ctx *ctx);   // wait for a pair in flight only (entry of the gravity walks)
 int ghip_finish_gas_tree(ghip_ctx *ctx);   // complete a deferred gas tree (entry of the SPH phases)
 #define GHIP_JOIN(ctx)                          \

@@ -1289,7 +1289,9 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   // starts, and the stream waits for that word -- from then on the slots the Ewald walk gives back stay
   // free, and hydro's wavefronts move in while the last Ewald ones finish (GHIP_HYDRO_TRIGGER=drain:
   // the kernel's end event instead).
-  if(ctx->grav_pending && !getenv("GHIP_HYDRO_EARLY"))
+  // (ghip_set_hydro_release(ctx, 1): at once -- for a host whose download of the SPH results then also
+  // runs underneath the walks, which is worth more than the 0.2 ms)
+  if(ctx->grav_pending && !ctx->hydro_early && !getenv("GHIP_HYDRO_EARLY"))
     {
       static int drain = -1;
       if(drain < 0)
@@ -1315,6 +1317,14 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
     P<double>(ctx->hpart), K, ng, P<double>(ctx->f[GHIP_F_HYDROACCEL]),
     P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]));
   HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+extern "C" int ghip_set_hydro_release(ghip_ctx *ctx, int early)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  ctx->hydro_early = early != 0;
   return GHIP_OK;
 }
 

@@ -125,6 +125,25 @@ static double wallclock(void)
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* GADGET_FORCE_TRACE=1: wall-clock stamps of the drivers' stages on stderr (development aid) */
+static int TraceOn = -1;
+static double TraceT0;
+static void trace(const char *what)
+{
+  if(TraceOn < 0)
+    {
+      const char *e = getenv("GADGET_FORCE_TRACE");
+      TraceOn = e && atoi(e) > 0;
+    }
+  if(!TraceOn)
+    return;
+  double t = wallclock();
+  if(!what)
+    TraceT0 = t;
+  else
+    fprintf(stderr, "[gadget_force] %-28s +%8.3f ms\n", what, 1e3 * (t - TraceT0));
+}
+
 /* endrun.c:23-38 */
 void endrun(int ierr)
 {
@@ -196,6 +215,11 @@ int gadget_force_init(const struct gadget_force_config *cfg)
   RcclConnected = 0;
   if(!RecP)
     lay_defaults();
+  /* (measured, not kept as the default: releasing the hydro kernel at once so that the SphP[] block
+   * crosses the link under the walks -- the kernel does not get its registers before the Ewald walk
+   * drains anyway; GADGET_FORCE_HYDRO_EARLY=1 reproduces it) */
+  if(cfg->overlap_sph && getenv("GADGET_FORCE_HYDRO_EARLY"))
+    ghip_set_hydro_release(Ctx, atoi(getenv("GADGET_FORCE_HYDRO_EARLY")));
   return GHIP_OK;
 }
 
@@ -595,9 +619,32 @@ static int upload_gas_if_pending(void)
   return chk(ghip_upload_aos_gas(Ctx, records_s(), &Lay), "ghip_upload_aos_gas") ? -1 : 0;
 }
 
-/* the active list as the reference threads it (run.c:300-320) */
+/* Everybody active, in index order?  (a full step: FirstActiveParticle = 0, NextActiveParticle[i] =
+ * i + 1, run.c:300-320.)  A pass without the list's load-to-load dependency. */
+static int active_list_is_everybody(void)
+{
+  if(NumPart <= 0 || FirstActiveParticle != 0 || !NextActiveParticle)
+    return 0;
+  int bad = 0;
+  const int *next = NextActiveParticle;
+  for(int i = 0; i < NumPart - 1; i++)
+    bad |= next[i] ^ (i + 1);
+  return bad == 0 && next[NumPart - 1] == -1;
+}
+
+/* the active list as the reference threads it (run.c:300-320); gas_only: the SPH drivers' filter
+ * P[i].Type == 0 (density.c:1049, hydra.c:184) on the gas block */
 static int collect_active(int gas_only)
 {
+  /* a full step needs no list: everybody for gravity; the whole gas block for SPH -- unless the
+   * upload found a converted particle in it (ghip_gas_block_mixed), then the list decides */
+  if(active_list_is_everybody())
+    {
+      if(!gas_only)
+        return NumPart;
+      if(DeviceFresh && ghip_gas_block_mixed(Ctx) == 0)
+        return N_gas;
+    }
   int n = 0;
   for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
     {
@@ -772,7 +819,15 @@ static int gravity_complete(int download)
   double comoving_fac = 0;
   if(!Cfg.periodic && !Cfg.pmgrid && All.ComovingIntegrationOn)
     comoving_fac = 0.5 * All.Hubble * All.Hubble * All.Omega0 / All.G;
-  if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
+  /* download == 2 (hydro_force with the walks in flight): post-pass and P[] block on the pair's own
+   * stream, next to the tail of the hydro kernel */
+  if(download == 2)
+    {
+      if(chk(ghip_gravity_to_records(Ctx, All.G, Cfg.pmgrid, comoving_fac, records_p(), &Lay),
+             "ghip_gravity_to_records"))
+        return -1;
+    }
+  else if(chk(ghip_gravity_finish_ex(Ctx, All.G, Cfg.pmgrid, comoving_fac, 0), "ghip_gravity_finish_ex"))
     return -1;
   if(All.TypeOfOpeningCriterion == 1)
     {
@@ -784,7 +839,7 @@ static int gravity_complete(int download)
     if(chk(ghip_gravity_vacuum_energy(Ctx, All.OmegaLambda * All.Hubble * All.Hubble),
            "ghip_gravity_vacuum_energy"))
       return -1;
-  if(download)
+  if(download == 1)
     {
       if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 1, 0, 0), "ghip_download_aos"))
         return -1;
@@ -819,6 +874,7 @@ void gravity_tree(void)
       return;
     }
   double t0 = wallclock();
+  trace(NULL);
   if(GravPending && gravity_complete(1))   /* accel.c:63-64: the second pass of step 0 needs OldAcc */
     return;
   /* gravtree.c:55-56 */
@@ -831,10 +887,12 @@ void gravity_tree(void)
   int nact = collect_active(0);
   if(nact < 0)
     return;
+  trace("gravity_tree: active list");
   /* overlap_sph: everything the walks read is in P[]; SphP[] follows once they are in flight */
   const int defer = Cfg.overlap_sph && Cfg.periodic && !Cfg.pmgrid && N_gas > 0 && nact == NumPart;
   if(ensure_tree_split(defer))
     return;
+  trace("gravity_tree: upload + tree");
   if(chk(ghip_set_active(Ctx, nact == NumPart ? NULL : ActiveBuf, nact == NumPart ? 0 : nact),
          "ghip_set_active"))
     return;
@@ -847,6 +905,7 @@ void gravity_tree(void)
     walk = GHIP_WALK_NEWTON_EWALD; /* both passes in one call: the two walks share the device */
   if(chk(ghip_gravity(Ctx, &g, walk), "ghip_gravity"))
     return;
+  trace("gravity_tree: walks launched");
   GravPendingActive = nact;
   /* overlap_sph: with gas to work on and everybody active (no list changes until hydro_force), the
    * walks stay in flight and the SPH phases run underneath them; the post-pass and the download
@@ -982,13 +1041,16 @@ void density(void)
   double t0 = wallclock();
   /* directly after gravity_tree() (accel.c:61-84) the device copy is current; a stand-alone
    * call (init.c:791) re-reads P/SphP */
+  trace(NULL);
   if(Phase != 1)
     DeviceFresh = 0;
   if(ensure_tree())
     return;
+  trace("density: gas upload");
   int nact = collect_active(1);
   if(nact < 0)
     return;
+  trace("density: active list");
   /* an empty list must not mean "all": give the device a real (possibly empty) list.  Everybody
    * active stays "everybody" (no list: a gravity pair in flight is not disturbed). */
   if(gravity_was_full_and_gas_is(nact))
@@ -1002,6 +1064,7 @@ void density(void)
   fill_dens_params(&d);
   if(chk(ghip_density(Ctx, &d), "ghip_density"))
     return;
+  trace("density: ghip_density");
   /* overlap_sph with the walks in flight: nothing reads the density results between density() and
    * hydro_force() (accel.c:84-106: force_update_hmax is ours), so they travel with the hydro results --
    * one download of the SphP[] block per step instead of two */
@@ -1041,6 +1104,7 @@ void hydro_force(void)
       return;
     }
   double t0 = wallclock();
+  trace(NULL);
   if(Phase != 2)
     DeviceFresh = 0;
   if(ensure_tree())
@@ -1048,6 +1112,7 @@ void hydro_force(void)
   int nact = collect_active(1);
   if(nact < 0)
     return;
+  trace("hydro_force: active list");
   if(gravity_was_full_and_gas_is(nact))
     {
       if(chk(ghip_set_active(Ctx, NULL, 0), "ghip_set_active"))
@@ -1059,16 +1124,36 @@ void hydro_force(void)
   fill_hydro_params(&h, 0);
   if(chk(ghip_hydro(Ctx, &h), "ghip_hydro"))
     return;
-  /* overlap_sph: the gravity walks have been running underneath; their post-pass now, and one
-   * download for both */
+  trace("hydro_force: ghip_hydro");
+  /* overlap_sph: the gravity walks have been running underneath.  The SphP[] block is queued behind
+   * the hydro kernel on the main stream; the walks' post-pass and the P[] block go on the pair's own
+   * stream, so that the P[] block crosses the link while hydro's tail still runs.  (Records with Hsml
+   * in P[] carry density results in the P[] block too: one download of everything then.) */
   const int with_gravity = GravPending;
-  if(with_gravity && gravity_complete(0))
-    return;
   const int with_density = DensPending;
   DensPending = 0;
-  if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, with_gravity, with_density, 1),
-         "ghip_download_aos"))
-    return;
+  if(with_gravity && Lay.p_hsml < 0 && !(Cfg.periodic == 0 && Cfg.pmgrid == 0))
+    {
+      if(chk(ghip_download_aos_async(Ctx, records_p(), records_s(), &Lay, 0, with_density, 1),
+             "ghip_download_aos_async"))
+        return;
+      if(gravity_complete(2))
+        return;
+      trace("hydro_force: P download");
+      if(chk(ghip_sync(Ctx), "ghip_sync"))
+        return;
+      trace("hydro_force: SphP download");
+    }
+  else
+    {
+      if(with_gravity && gravity_complete(0))
+        return;
+      trace("hydro_force: walks joined");
+      if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, with_gravity, with_density, 1),
+             "ghip_download_aos"))
+        return;
+      trace("hydro_force: download");
+    }
   Phase = 0;
   CPU_Step_Hydro += wallclock() - t0;
 }
@@ -1866,10 +1951,7 @@ static void density_ranks(void)
   int nact = collect_active(1);
   if(nact < 0)
     return;
-  int nact_all = 0;
-  for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
-    nact_all++;
-  if(set_active_list(nact, nact_all == NumPart))
+  if(set_active_list(nact, active_list_is_everybody()))
     return;
   ghip_dens_params d;
   fill_dens_params(&d);

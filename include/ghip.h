@@ -261,6 +261,20 @@ int ghip_upload_aos_particles(ghip_ctx *ctx, const void *P, const ghip_layout *l
 int ghip_upload_aos_gas(ghip_ctx *ctx, const void *SphP, const ghip_layout *lay);
 int ghip_download_aos(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay,
                       int want_gravity, int want_density, int want_hydro);
+/* ghip_download_aos without the wait at its end: the packing kernels and the copies are queued on the
+ * library's stream; the arrays are complete after the next synchronising call (ghip_sync). */
+int ghip_download_aos_async(ghip_ctx *ctx, void *P, void *SphP, const ghip_layout *lay,
+                            int want_gravity, int want_density, int want_hydro);
+/* gravity_tree()'s post-pass (ghip_gravity_finish_ex with these arguments) and the gravity fields of
+ * the P[] block (ghip_download_aos(..., 1, 0, 0)) in one call that, with a GHIP_WALK_NEWTON_EWALD pair
+ * in flight, is ordered after the pair ONLY -- not behind SPH kernels queued underneath it, whose tail
+ * the copy then overlaps.  Returns with P[] complete. */
+int ghip_gravity_to_records(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac, void *P,
+                            const ghip_layout *lay);
+/* After ghip_upload_aos / ghip_upload_aos_particles: 1 when a record of the gas block [0, ngas) has a
+ * Type other than 0 (a particle converted since the last rearrange_particle_sequence(); the block is
+ * gas by allvars.h:1384), else 0.  Lets a host skip its own pass over P[].Type. */
+int ghip_gas_block_mixed(ghip_ctx *ctx);
 /* Page-lock a host array the record copies go through (the reference allocates P[] / SphP[] once
  * for All.MaxPart, allocate.c:30-60): the copies then run at the link's rate instead of through
  * the runtime's staging buffers.  Optional; a range that cannot be locked is left as it is
@@ -538,6 +552,11 @@ int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p);
 int ghip_density(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_update_hmax(ghip_ctx *ctx);
 int ghip_hydro(ghip_ctx *ctx, const ghip_hydro_params *p);
+/* When ghip_hydro is called underneath a GHIP_WALK_NEWTON_EWALD pair in flight, its kernel is held
+ * back on the device until the Ewald walk drains (fastest step for resident data).  early != 0: it
+ * starts at once -- the step's kernels take 0.2 ms longer at c2, but a host that downloads the SPH
+ * results gets them across while the walks still run. */
+int ghip_set_hydro_release(ghip_ctx *ctx, int early);
 
 /* one fixed-h evaluation for a single target (density_evaluate mode 0, density.c:711):
  * out7 = rho, numngb, dhsmlrho, divv, rot[3] (raw sums, before finalisation) */
