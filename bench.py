@@ -341,6 +341,45 @@ def main():
             iso_int = s2["grav_interactions"]
         iso_ms, iso_steps = float(np.median(iso)), float(np.median(isteps))
 
+    # a rank's share of a step phase by phase (outside the timed region; the device drained between
+    # phases, so the numbers add up -- unlike the overlapping spans of the timed steps)
+    shard_phases = None
+    if dom is not None:
+        for _ in range(2):
+            dp = pr.g_dens()
+            if not args.frozen:
+                fp.drift(tl.next_sync_point(), tl.tb, box_wrap=True, boxsize=pr.box)
+            dp.Ti_Current, dp.Timebase_interval = tl.ti, tl.tb
+            rows = []
+            c, x = dom.timed(B.DD_MIGRATE, None)
+            rows += [("migrate", sum(c)), ("migrate: exchange", sum(x))]
+            c, x = dom.timed(B.DD_GRAVITY, gp_rel, B.WALK_NEWTON_EWALD)
+            names = ["gravity: own tree + groups", "gravity: LET selection + packing",
+                     "gravity: merged tree + both walks"]
+            rows += [(names[i] if i < 3 else "gravity: phase %d" % i, v) for i, v in enumerate(c)]
+            rows.append(("gravity: exchanges", sum(x)))
+            c, x = dom.timed(B.DD_DENSITY, dp)
+            names = ["density: gas groups", "density: ghost selection",
+                     "density: gas tree + h iteration", "density: refresh of the ghosts' hosts"]
+            rows += [(names[i] if i < 4 else "density: phase %d" % i, v) for i, v in enumerate(c)]
+            rows.append(("density: exchanges", sum(x)))
+            fp.sync()
+            t1 = time.perf_counter()
+            fp.update_hmax()
+            fp.sync()
+            rows.append(("force_update_hmax", 1e3 * (time.perf_counter() - t1)))
+            c, x = dom.timed(B.DD_HYDRO, hp)
+            rows += [("hydro", sum(c)), ("hydro: exchanges", sum(x))]
+            fp.gravity_finish(pr.G)
+            if not args.frozen:
+                fp.advance_timesteps(tl.kick_params(), counts=False)
+            fp.sync()
+        vals = [v for _, v in rows]
+        vmax = allreduce(vals, dist.ReduceOp.MAX)
+        vsum = allreduce(vals, dist.ReduceOp.SUM)
+        shard_phases = {nm: {"max": a, "mean": b / world} for (nm, _), a, b in zip(rows, vmax, vsum)}
+        shard_phases["sum_of_slowest"] = sum(vmax)
+
     ms_per_step = 1e3 * elapsed / K
     value = n_total * K / elapsed
 
@@ -392,6 +431,7 @@ def main():
         if dom is not None:
             out["transport"] = transport     # "rccl": RCCL from C (ghip_dd_run); "host": staged through gloo
             out["rccl_library"] = B.dd_rccl_library() if transport == "rccl" else None
+            out["shard_phases_ms"] = shard_phases
             out["exchange_per_step_rank0"] = {
                 "particles_migrated": migrated / K,
                 "bytes_sent_migration": dd_bytes[0] / K,
@@ -461,7 +501,7 @@ def walk_roofline(work, phase_ms, K, st, iso_ms, iso_steps, args, world, grav_in
     kern_s = 1e-3 * phase_ms["grav"] / K
     wave_steps = work["grav_wave_steps"] / K
     pmc = None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         f = os.path.join(HERE, "profiles", "%s_walk_valu.json" % tag)
         if os.path.exists(f):
             try:

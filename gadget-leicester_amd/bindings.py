@@ -698,9 +698,10 @@ class ForcePath:
     def dd_exchange(self):
         self._chk(self.L.ghip_dd_exchange(self.h))
 
-    def dd_run_host(self, op, params, allgather, walk=0):
-        """The operation with every exchange staged through the host and `allgather(send: bytes)
-        -> bytes of all ranks, rank-major` (ghip_dd_exchange_host)."""
+    @staticmethod
+    def allgather_callback(allgather):
+        """`allgather(send: bytes) -> bytes of all ranks, rank-major` as the C callback of
+        ghip_dd_exchange_host (keep the returned object alive while it is in use)."""
         def cb(_user, send, nbytes, recv):
             try:
                 data = C.string_at(send, nbytes)
@@ -711,7 +712,15 @@ class ForcePath:
                 import traceback
                 traceback.print_exc()
                 return 1
-        fn = ALLGATHER_CB(cb)
+        return ALLGATHER_CB(cb)
+
+    def dd_exchange_host(self, fn):
+        self._chk(self.L.ghip_dd_exchange_host(self.h, fn, None))
+
+    def dd_run_host(self, op, params, allgather, walk=0):
+        """The operation with every exchange staged through the host and `allgather(send: bytes)
+        -> bytes of all ranks, rank-major` (ghip_dd_exchange_host)."""
+        fn = self.allgather_callback(allgather)
         self.dd_begin(op, params, walk)
         while True:
             rc = self.dd_step()

@@ -248,6 +248,14 @@ extern "C" int ghip_create(int device, ghip_ctx **out)
       delete ctx;
       return GHIP_ENOMEM;
     }
+  if(ghip_ensure(ctx, ctx->cslots, GHIP_CBUF_BYTES) != GHIP_OK ||
+     ghip_ensure(ctx, ctx->rslots, GHIP_CBUF_BYTES) != GHIP_OK ||
+     hipMemset(ctx->cslots.p, 0, GHIP_CBUF_BYTES) != hipSuccess ||
+     hipMemset(ctx->rslots.p, 0, GHIP_CBUF_BYTES) != hipSuccess)
+    {
+      delete ctx;
+      return GHIP_ENOMEM;
+    }
   // pinned, device-visible host words: tree-build read-back [0..7], device error words [32..39]
   if(hipHostMalloc(&ctx->pinned, 1024, hipHostMallocDefault) != hipSuccess)
     {
@@ -306,7 +314,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
                   &ctx->ddivv,  &ctx->drot,   &ctx->dflags,  &ctx->dtgt_a,  &ctx->dtgt_b,
                   &ctx->act_host_idx, &ctx->tg_grav, &ctx->tg_gas, &ctx->tax, &ctx->tay,
                   &ctx->taz,    &ctx->tcost,  &ctx->ewtab,   &ctx->ewbrick, &ctx->srtab,   &ctx->cubtmp,
-                  &ctx->counters, &ctx->dhcur, &ctx->hpart, &ctx->plan_nsub, &ctx->plan_woff,
+                  &ctx->counters, &ctx->cslots, &ctx->rslots, &ctx->dhcur, &ctx->hpart, &ctx->plan_nsub, &ctx->plan_woff,
                   &ctx->plan_wave, &ctx->plan_steps[0][0], &ctx->plan_steps[0][1],
                   &ctx->plan_steps[1][0], &ctx->plan_steps[1][1], &ctx->plan_steps[2][0],
                   &ctx->plan_steps[2][1], &ctx->tax2, &ctx->tay2, &ctx->taz2, &ctx->tcost2,
@@ -1103,6 +1111,21 @@ extern "C" int ghip_set_adaptive_gravsoft(ghip_ctx *ctx, int on)
   return GHIP_OK;
 }
 
+int ghip_read_slots(ghip_ctx *ctx, DevBuf &buf, unsigned long long out[GHIP_CK_COUNT][2])
+{
+  std::vector<unsigned long long> h((size_t) GHIP_CK_COUNT * GHIP_CKIND_U64);
+  HIPCHK(hipMemcpy(h.data(), buf.p, GHIP_CBUF_BYTES, hipMemcpyDeviceToHost));
+  for(int k = 0; k < GHIP_CK_COUNT; k++)
+    for(int w = 0; w < 2; w++)
+      {
+        unsigned long long t = 0;
+        for(int s = 0; s < GHIP_CSLOTS; s++)
+          t += h[(size_t) k * GHIP_CKIND_U64 + (size_t) s * GHIP_CSLOT_U64 + w];
+        out[k][w] = t;
+      }
+  return GHIP_OK;
+}
+
 extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
 {
   ghip_ctx *ctx = const_cast<ghip_ctx *>(cctx);
@@ -1111,16 +1134,16 @@ extern "C" int ghip_get_stats(const ghip_ctx *cctx, ghip_stats *out)
   GHIP_JOIN(ctx);
   HIPCHK(ghip_stream_sync(ctx, ctx->stream));
   ghip_stats &S = ctx->stats;
-  if(ctx->counters.p)
+  if(ctx->cslots.p)
     {
-      unsigned long long c[16];
-      HIPCHK(hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
-      S.grav_wave_steps = (long long) c[8];
-      S.ewald_wave_steps = (long long) c[9];
-      S.grav_interactions = (long long) c[0];
-      S.ewald_interactions = (long long) c[1];
-      S.dens_neighbours = (long long) c[4];
-      S.hydro_pairs = (long long) c[6];
+      unsigned long long c[GHIP_CK_COUNT][2];
+      GCHK(ghip_read_slots(ctx, ctx->cslots, c));
+      S.grav_wave_steps = (long long) c[GHIP_CK_NEWTON][1];
+      S.ewald_wave_steps = (long long) c[GHIP_CK_EWALD][1];
+      S.grav_interactions = (long long) c[GHIP_CK_NEWTON][0];
+      S.ewald_interactions = (long long) c[GHIP_CK_EWALD][0];
+      S.dens_neighbours = (long long) c[GHIP_CK_DENS][0];
+      S.hydro_pairs = (long long) c[GHIP_CK_HYDRO][0];
     }
   auto el = [&](int a, int b) {
     float ms = 0;
@@ -1161,16 +1184,6 @@ extern "C" int ghip_set_async(ghip_ctx *ctx, int on)
 // ---------------------------------------------------------------------------------------------
 #define RUN_EV (GHIP_NEV + 2)   // events per ring slot: the phase events + step begin / end marks
 
-// counters of the step's calls (each phase resets its own at its start) summed into the run's
-__global__ void k_run_accumulate(const unsigned long long *__restrict__ c, unsigned long long *__restrict__ acc)
-{
-  // (the walks add to acc[0], [1], [4], [5] themselves: interactions and element visits)
-  if(threadIdx.x == 0)
-    acc[2] += c[4];   // neighbours of the step's density passes
-  if(threadIdx.x == 1)
-    acc[3] += c[6];   // pairs of its hydro pass
-}
-
 extern "C" int ghip_run_begin(ghip_ctx *ctx, int max_steps)
 {
   if(!ctx || max_steps < 1)
@@ -1190,7 +1203,8 @@ extern "C" int ghip_run_begin(ghip_ctx *ctx, int max_steps)
   ctx->run_dens_iter = 0;
   ctx->run_syncs0 = ctx->n_syncs;
   ctx->run_launches0 = ghip_launch_count();
-  HIPCHK(hipMemsetAsync(ctx->run_acc.p, 0, 16 * 8, ctx->stream));
+  // (the walks and the SPH kernels add to the run's counter slots themselves)
+  HIPCHK(hipMemsetAsync(ctx->rslots.p, 0, GHIP_CBUF_BYTES, ctx->stream));
   return GHIP_OK;
 }
 
@@ -1210,9 +1224,6 @@ extern "C" int ghip_step_end(ghip_ctx *ctx)
   if(!ctx || ctx->ring_slots <= 0 || ctx->ring_cur < 0)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_step_end: no step in progress");
   GCHK(ghip_join_pair(ctx));   // (a gravity pair still in flight belongs to this step)
-  k_run_accumulate<<<1, 64, 0, ctx->stream>>>(P<unsigned long long>(ctx->counters),
-                                              P<unsigned long long>(ctx->run_acc));
-  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evp[GHIP_NEV + 1], ctx->stream));
   ctx->run_steps++;
   ctx->run_dens_iter += ctx->stats.dens_iterations;
@@ -1228,15 +1239,15 @@ extern "C" int ghip_run_end(ghip_ctx *ctx, ghip_run_stats *out)
   out->blocking_syncs = ctx->n_syncs - ctx->run_syncs0;
   GHIP_JOIN(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  unsigned long long acc[6];
-  HIPCHK(hipMemcpy(acc, ctx->run_acc.p, sizeof(acc), hipMemcpyDeviceToHost));
+  unsigned long long acc[GHIP_CK_COUNT][2];
+  GCHK(ghip_read_slots(ctx, ctx->rslots, acc));
   out->steps = ctx->run_steps;
-  out->grav_interactions = (long long) acc[0];
-  out->ewald_interactions = (long long) acc[1];
-  out->dens_neighbours = (long long) acc[2];
-  out->hydro_pairs = (long long) acc[3];
-  out->grav_wave_steps = (long long) acc[4];
-  out->ewald_wave_steps = (long long) acc[5];
+  out->grav_interactions = (long long) acc[GHIP_CK_NEWTON][0];
+  out->ewald_interactions = (long long) acc[GHIP_CK_EWALD][0];
+  out->dens_neighbours = (long long) acc[GHIP_CK_DENS][0];
+  out->hydro_pairs = (long long) acc[GHIP_CK_HYDRO][0];
+  out->grav_wave_steps = (long long) acc[GHIP_CK_NEWTON][1];
+  out->ewald_wave_steps = (long long) acc[GHIP_CK_EWALD][1];
   out->dens_extra_iterations = ctx->run_dens_iter;
   auto el = [](hipEvent_t a, hipEvent_t b) {
     float ms = 0;

@@ -473,12 +473,9 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, i
   int cur = ctx->plan_cur[kind];
   unsigned int *prev = P<unsigned int>(ctx->plan_steps[kind][cur]);
   unsigned int *out = P<unsigned int>(ctx->plan_steps[kind][cur ^ 1]);
-  // total of the previous call of this kind (the walk accumulates it in counters[8 + kind]);
-  // saved before the caller clears the counter
-  unsigned long long *total_prev = P<unsigned long long>(ctx->counters) + 56 + kind;
-  if(have_prev)
-    HIPCHK(hipMemcpyAsync(total_prev, P<unsigned long long>(ctx->counters) + 8 + kind, 8,
-                          hipMemcpyDeviceToDevice, st));
+  // total of the previous call of this kind (the walk accumulates it in the kind's counter slots,
+  // which the caller clears after this -- on the same stream)
+  unsigned long long *total_prev = ghip_cslot(ctx, kind);
   k_plan_nsub<<<cdiv(nb, 256), 256, 0, st>>>(nb, ns, sbase, prev, total_prev, have_prev,
                                              P<int>(b_nsub));
   size_t tb = 0;
@@ -565,9 +562,8 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   k_grav_walk<MODE, PER, UNEQ><<<blocks, bsize, dyn_lds, stream>>>(                                \
     t.nelem, P<WalkHot>(t.mq), P<WalkCold>(t.mq2), sg, nt, tgt, tx, ty, tz, tsoft, toldacc, k,     \
     P<float>(ctx->srtab), P<double>((UNEQ) && MODE == GHIP_WALK_EWALD ? ctx->ewbrick : ctx->ewtab),  \
-    pb.ax, pb.ay, pb.az, pb.cost, counter,                                                         \
-    P<unsigned long long>(ctx->run_acc) + (counter - P<unsigned long long>(ctx->counters) < 2       \
-                                             ? counter - P<unsigned long long>(ctx->counters) : 8), pl)
+    pb.ax, pb.ay, pb.az, pb.cost, getenv("GHIP_WALK_NOCOUNT") ? nullptr : counter,                  \
+    P<unsigned long long>(ctx->rslots) + (counter - P<unsigned long long>(ctx->cslots)), pl)
   // The Ewald walk has no softening rule; its UNEQUAL instantiation is the variant that reads the
   // brick-tiled table (the default; GHIP_EW_BRICK=0 selects the plain rows).  Alone the walk is bound
   // by the L2 requests of its gathers and the bricks cut them (6.3 -> 4.5 ms at c2); inside a pair
@@ -638,9 +634,8 @@ static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int n
   walk_layout(ctx->gt, nt, J.sg, &J.nbuckets, walk == GHIP_WALK_EWALD);
   GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, J.nbuckets, J.sg.ns, J.plan, slot, ps));
   GCHK(ensure_partials(ctx, J.plan.nwaves, slot, J.pb));
-  J.counter = P<unsigned long long>(ctx->counters) + (walk == GHIP_WALK_EWALD ? 1 : 0);
-  HIPCHK(hipMemsetAsync(J.counter, 0, 8, ps));
-  HIPCHK(hipMemsetAsync(J.counter + 8, 0, 8, ps));
+  J.counter = ghip_cslot(ctx, walk == GHIP_WALK_EWALD ? GHIP_CK_EWALD : GHIP_CK_NEWTON);
+  HIPCHK(hipMemsetAsync(J.counter, 0, GHIP_CKIND_U64 * 8, ps));
   return GHIP_OK;
 }
 
@@ -739,11 +734,27 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   E.plan.started = started;
   GCHK(run_walk(ctx, E, nt, tgt, sE));
   HIPCHK(hipEventRecord(ctx->evx[3], sE));   // the Ewald walk's wavefront slots are free from here on
-  GCHK(combine_walk(ctx, A, nt, tgt, sN));
-  HIPCHK(hipEventRecord(ctx->evx[1], sN));
-  HIPCHK(hipStreamWaitEvent(sE, ctx->evx[1], 0));
-  GCHK(combine_walk(ctx, E, nt, tgt, sE));
+  if(A.k.debug_steps || E.k.debug_steps || getenv("GHIP_PAIR_TWO_COMBINES"))
+    {
+      GCHK(combine_walk(ctx, A, nt, tgt, sN));
+      HIPCHK(hipEventRecord(ctx->evx[1], sN));
+      HIPCHK(hipStreamWaitEvent(sE, ctx->evx[1], 0));
+      GCHK(combine_walk(ctx, E, nt, tgt, sE));
+    }
+  else
+    {
+      // both sums in one launch behind the later walk (the Newtonian one, as the pair is balanced)
+      HIPCHK(hipEventRecord(ctx->evx[1], sN));
+      HIPCHK(hipStreamWaitEvent(sE, ctx->evx[1], 0));
+      k_combine_pair<<<cdiv(nt, 256), 256, 0, sE>>>(
+        nt, A.plan, E.plan, tgt, P<int>(ctx->gt.perm), A.pb.ax, A.pb.ay, A.pb.az, A.pb.cost, E.pb.ax,
+        E.pb.ay, E.pb.az, E.pb.cost, ctx->n, P<double>(ctx->f[GHIP_F_GRAVACCEL]),
+        P<int>(ctx->f[GHIP_F_GRAVCOST]));
+      HIPCHK(hipGetLastError());
+    }
   HIPCHK(hipEventRecord(ctx->evx[2], sE));
+  // (the Newtonian walk's stream builds the NEXT plan in place -- after the combine has read this one)
+  HIPCHK(hipStreamWaitEvent(sN, ctx->evx[2], 0));
   ctx->grav_pending = true;
   ctx->pair_started = started;
   return GHIP_OK;
@@ -804,7 +815,7 @@ extern "C" int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, i
   GCHK(build_plan(ctx, 2, nbuckets, sg.ns, plan));
   PartialBufs pb;
   GCHK(ensure_partials(ctx, plan.nwaves, 0, pb));
-  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 2;
+  unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_EXT);
   launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
                   counter, plan, pb, st);
   k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, plan, nullptr, nullptr, P<double>(ctx->tax),

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ghip.h"
+#include "ghip_count.h"
 
 #define GHIP_BITS 21       // BITS_PER_DIMENSION, allvars.h:58
 #define GHIP_EN 64         // EN, forcetree.c:51
@@ -309,6 +310,9 @@ struct ghip_ctx
   DevBuf pm_rho, pm_k, pm_force;
   // counters (device): 8 x u64
   DevBuf counters;
+  // work counters of the walks and the SPH kernels, 64 slots per kind (ghip_count.h): of the current
+  // calls (each call of a kind clears its own) and of the run (ghip_run_begin clears)
+  DevBuf cslots, rslots;
   ghip_stats stats;
   hipEvent_t ev[16];
   DDState dd;                // multi-GPU domain decomposition (ghip_dd.hip)
@@ -401,6 +405,16 @@ static inline int *ghip_gas_mixed_word(ghip_ctx *ctx)
 {
   return reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->pinned) + 256);
 }
+static inline unsigned long long *ghip_cslot(ghip_ctx *ctx, int kind)
+{
+  return reinterpret_cast<unsigned long long *>(ctx->cslots.p) + (size_t) kind * GHIP_CKIND_U64;
+}
+static inline unsigned long long *ghip_rslot(ghip_ctx *ctx, int kind)
+{
+  return reinterpret_cast<unsigned long long *>(ctx->rslots.p) + (size_t) kind * GHIP_CKIND_U64;
+}
+// host copy of a slot buffer added up: out[kind][which], which = 0, 1
+int ghip_read_slots(ghip_ctx *ctx, DevBuf &buf, unsigned long long out[GHIP_CK_COUNT][2]);
 int ghip_gravity_finish_on(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac, int all_shards,
                            hipStream_t st);
 int ghip_join_pair(ghip_ctx *ctx);   // wait for a pair in flight only (entry of the gravity walks)

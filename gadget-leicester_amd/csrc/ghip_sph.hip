@@ -278,7 +278,7 @@ k_density(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, c
           int nsub, const int *__restrict__ tgt, const double *__restrict__ hcur, BoxK b,
           double *__restrict__ prho, double *__restrict__ pnum, double *__restrict__ pdh,
           double *__restrict__ pdiv, double *__restrict__ prot,
-          unsigned long long *__restrict__ counter)
+          unsigned long long *__restrict__ counter, unsigned long long *__restrict__ racc)
 {
   constexpr int CS = 64 / TG;
   __shared__ double4 sh[SPH_STAGE][2];
@@ -380,7 +380,10 @@ k_density(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, c
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.nn);
   if(lane == 0 && tot)
-    atomicAdd(counter, tot);
+    {
+      d_count(counter, 0, tot);
+      d_count(racc, 0, tot);
+    }
 }
 
 // SphNode records from the gas tree's arrays; k_sph_nodes_hmax refreshes only hmax
@@ -744,9 +747,10 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
   TreeDev &t = ctx->st;
   GCHK(dens_alloc(ctx));
   double *hcur = P<double>(ctx->dhcur);
-  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 4;
+  unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_DENS);
+  unsigned long long *racc = ghip_rslot(ctx, GHIP_CK_DENS);
   int *dnum = reinterpret_cast<int *>(P<unsigned long long>(ctx->counters) + 32);
-  HIPCHK(hipMemsetAsync(counter, 0, 8, st));
+  HIPCHK(hipMemsetAsync(counter, 0, GHIP_CKIND_U64 * 8, st));
   HIPCHK(hipEventRecord(ctx->evp[6], st));
 
   int *cur = P<int>(ctx->dtgt_a), *nxt = P<int>(ctx->dtgt_b);
@@ -772,7 +776,7 @@ int ghip_density_impl(ghip_ctx *ctx, const ghip_dens_params *p)
       nsub = nsub < 1 ? 1 : (nsub > GHIP_MAXSUB ? GHIP_MAXSUB : nsub);
       SPH_LAUNCH(k_density, tgw, nbk * nsub, st, P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp), ncur,
                  nsub, cur, hcur, b, P<double>(ctx->drho), P<double>(ctx->dnumngb),
-                 P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), counter);
+                 P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), counter, racc);
       k_dens_finalize<<<cdiv(ncur, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(
         ncur, nsub, cur, P<int>(t.perm), n, ng, F, P<double>(ctx->drho), P<double>(ctx->dnumngb),
         P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot), hcur,
@@ -860,11 +864,11 @@ extern "C" int ghip_density_evaluate(ghip_ctx *ctx, const ghip_dens_params *p, i
   HIPCHK(hipMemcpyAsync(cur, &s, 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(hcur + s, &h, 8, hipMemcpyHostToDevice, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
-  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 5;
+  unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_DENS1);
   k_density<8><<<nsub, 64, 0, st>>>(P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp), 1, nsub, cur, hcur, b,
                               P<double>(ctx->drho), P<double>(ctx->dnumngb),
                               P<double>(ctx->ddhsml), P<double>(ctx->ddivv), P<double>(ctx->drot),
-                              counter);
+                              counter, ghip_rslot(ctx, GHIP_CK_DENS1));
   HIPCHK(hipGetLastError());
   // nt == 1: partial q of component c sits at [q] (rot: [c*nsub + q]); sum in fixed order
   double part[7][GHIP_MAXSUB * 8];
@@ -1091,7 +1095,8 @@ template <int TG>
 __global__ void __launch_bounds__(64)
 k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, const double *__restrict__ gp,
         const double *__restrict__ gq, int nt, int nsub, const int *__restrict__ tgt, BoxK b, HydK K,
-        double *__restrict__ part, unsigned long long *__restrict__ counter)
+        double *__restrict__ part, unsigned long long *__restrict__ counter,
+        unsigned long long *__restrict__ racc)
 {
   constexpr int CS = 64 / TG;
   __shared__ double4 sh[SPH_STAGE][4];
@@ -1222,7 +1227,10 @@ k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, con
     }
   unsigned long long tot = d_wave_sum_u64((unsigned long long) A.np);
   if(lane == 0 && tot)
-    atomicAdd(counter, tot);
+    {
+      d_count(counter, 0, tot);
+      d_count(racc, 0, tot);
+    }
 }
 
 // fixed-order sum of the partial results + the entropy-rate conversion of hydro_force
@@ -1277,8 +1285,8 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   hipStream_t st = ctx->stream;
   TreeDev &t = ctx->st;
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
-  unsigned long long *counter = P<unsigned long long>(ctx->counters) + 6;
-  HIPCHK(hipMemsetAsync(counter, 0, 8, st));
+  unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_HYDRO);
+  HIPCHK(hipMemsetAsync(counter, 0, GHIP_CKIND_U64 * 8, st));
   BoxK b = {p->BoxSize, 0.5 * p->BoxSize, p->periodic};
   HydK K = {p->ArtBulkViscConst, p->hubble_a2, p->fac_mu, p->fac_vsic_fix, p->Timebase_interval,
             p->ComovingIntegrationOn, p->raw_dtentropy};
@@ -1309,7 +1317,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   GCHK(ghip_ensure(ctx, ctx->hpart, (size_t) 5 * nsub * nt * 8));
   SPH_LAUNCH(k_hydro, tgw, nbk * nsub, st, P<TreeSizes>(t.dsz), P<SphNode>(t.mq), P<double>(ctx->gp),
              P<double>(ctx->gq), nt, nsub, P<int>(ctx->tg_gas) + lo, b, K, P<double>(ctx->hpart),
-             counter);
+             counter, ghip_rslot(ctx, GHIP_CK_HYDRO));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evp[11], st));
   k_hydro_combine<<<cdiv(nt, ghip_wg(ctx)), ghip_wg(ctx), 0, st>>>(

@@ -31,6 +31,7 @@
 // No MFMA: irregular fp64 work.
 #pragma once
 #include "ghip_internal.h"
+#include "ghip_count.h"
 
 #ifndef GHIP_WALK_WAVES
 #define GHIP_WALK_WAVES 8   // wavefronts per SIMD the register allocator must leave room for
@@ -869,15 +870,19 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   // counter: this call's totals (reset by the next call of the kind); acc: the run's (ghip_run_begin),
   // kept by the kernel itself -- the next call's reset is enqueued on this walk's stream and may
   // overtake whatever the main stream would do with the counters at the end of a step
-  if(lane == 0 && tot)
+  // (64 slots each, ghip_count.h: no address that every wavefront of the launch hits)
+  if(lane == 0 && tot && counter)
     {
-      atomicAdd(counter, tot);
-      atomicAdd(acc, tot);
+      d_count(counter, 0, tot);
+      d_count(acc, 0, tot);
     }
   if(lane == 0)
     {
-      atomicAdd(counter + 8, (unsigned long long) steps);
-      atomicAdd(acc + 4, (unsigned long long) steps);
+      if(counter)
+        {
+          d_count(counter, 1, (unsigned long long) steps);
+          d_count(acc, 1, (unsigned long long) steps);
+        }
       atomicAdd(plan.steps_out + bucket, steps);   // cost model of the next call's plan
     }
 }
@@ -900,7 +905,11 @@ __global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__res
   int s = ns < sbase ? ns : sbase;
   if(have_prev)
     {
-      double mean = (double) (*total_prev) / (double) nb;
+      // element visits of the previous call of the kind: its 64 counter slots added up
+      unsigned long long tot = 0;
+      for(int k = 0; k < GHIP_CSLOTS; k++)
+        tot += total_prev[k * GHIP_CSLOT_U64 + 1];
+      double mean = (double) tot / (double) nb;
       if(mean > 0)
         {
           s = (int) ((double) sbase * (double) steps_prev[b] / mean) + 1;
@@ -914,7 +923,7 @@ __global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__res
 }
 
 // The grid and the partial-sum buffers are sized for maxwaves = (S+2)*nb + 8 wavefronts, which
-// bounds sum(nsub) only while counters[8+kind] equals the sum of steps_prev[] (both are written by
+// bounds sum(nsub) only while the kind's visit counter equals the sum of steps_prev[] (both are written by
 // the same previous launch).  Should that invariant ever break, wavefronts beyond maxwaves would
 // not exist while k_combine_grav still summed their slots: the plan is therefore checked here and
 // an overflow is a hard error (GHIP_E_PLAN in the context's device error word, reported by the
@@ -1029,6 +1038,58 @@ __global__ void k_combine_grav(int nt, WalkPlan plan, const int *__restrict__ tg
       oacc[2 * (size_t) n + i] = a2;
       ocost[i] = c;
     }
+}
+
+// The same for a Newton + Ewald pair in one pass: GravAccel = (Newtonian sum) + (Ewald sum), as the
+// two calls leave it (the second one adds its sum to the first one's, forcetree.c:3190-3193) -- one
+// launch behind the later of the two walks instead of two in a row.
+__global__ void k_combine_pair(int nt, WalkPlan pn, WalkPlan pe, const int *__restrict__ tgt,
+                               const int *__restrict__ perm, const double *__restrict__ nax,
+                               const double *__restrict__ nay, const double *__restrict__ naz,
+                               const int *__restrict__ ncost, const double *__restrict__ eax,
+                               const double *__restrict__ eay, const double *__restrict__ eaz,
+                               const int *__restrict__ ecost, int n, double *__restrict__ oacc,
+                               int *__restrict__ ocost)
+{
+  int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if(ti >= nt)
+    return;
+  const int bucket = ti >> 6, lane = ti & 63;
+  double a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+  int c = 0, d = 0;
+  {
+    const int w0 = pn.woff[bucket];
+    int nsub = pn.nsub[bucket];
+    if(w0 + nsub > pn.nwaves)
+      nsub = pn.nwaves > w0 ? pn.nwaves - w0 : 0;
+    for(int s = 0; s < nsub; s++)
+      {
+        size_t o = (size_t) (w0 + s) * 64 + lane;
+        a0 += nax[o];
+        a1 += nay[o];
+        a2 += naz[o];
+        c += ncost[o];
+      }
+  }
+  {
+    const int w0 = pe.woff[bucket];
+    int nsub = pe.nsub[bucket];
+    if(w0 + nsub > pe.nwaves)
+      nsub = pe.nwaves > w0 ? pe.nwaves - w0 : 0;
+    for(int s = 0; s < nsub; s++)
+      {
+        size_t o = (size_t) (w0 + s) * 64 + lane;
+        b0 += eax[o];
+        b1 += eay[o];
+        b2 += eaz[o];
+        d += ecost[o];
+      }
+  }
+  int i = perm ? perm[tgt[ti]] : ti;
+  oacc[i] = a0 + b0;
+  oacc[(size_t) n + i] = a1 + b1;
+  oacc[2 * (size_t) n + i] = a2 + b2;
+  ocost[i] = c + d;
 }
 
 // the walk's hot/cold element records from the tree arrays (see WalkHot / WalkCold)

@@ -219,6 +219,35 @@ class DomainRank:
         else:
             self.p.dd_run_host(op, params, self.allgather, walk)
 
+    def timed(self, op, params, walk=0):
+        """The operation phase by phase with the device drained in between (measurement only):
+        returns ([compute ms per phase], [exchange ms per exchange])."""
+        import time
+        p = self.p
+        p.dd_begin(op, params, walk)
+        comp, exch = [], []
+        cb = None
+        if self.transport != "rccl":
+            cb = p.allgather_callback(self.allgather)
+        while True:
+            p.sync()
+            t0 = time.perf_counter()
+            rc = p.dd_step()
+            p.sync()
+            comp.append(1e3 * (time.perf_counter() - t0))
+            if rc == 0:
+                break
+            t0 = time.perf_counter()
+            if cb is None:
+                p.dd_exchange()
+            else:
+                p.dd_exchange_host(cb)
+            p.sync()
+            exch.append(1e3 * (time.perf_counter() - t0))
+        if op == self.B.DD_MIGRATE:
+            p.counts()
+        return comp, exch
+
     def gravity(self, params, walk):
         self._run(self.B.DD_GRAVITY, params, walk)
 

@@ -99,10 +99,21 @@ def main():
             if line.startswith('{"metric"'):
                 rec = json.loads(line)
                 steps = rec["work_per_step_rank0"]["grav_wave_steps"]
+                # the launches of the TIMED steps only (the visits the bench line reports are theirs):
+                # launch 0 is the Barnes-Hut pass, 1 the first relative-criterion pass, then the
+                # warm-up steps, then the timed ones; later launches (the kernel alone, the drop-in
+                # legs) run on the state the run reached and would bias the mean
+                first = 2 + int(rec["warmup"])
+                vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(csvf))
+                        if r["Kernel_Name"].startswith(KERNELS["k_grav_walk<NEWTON>"])
+                        and r["Counter_Name"] == "SQ_INSTS_VALU"]
+                timed = vals[first:first + int(rec["steps"])]
+                per_launch = sum(timed) / len(timed)
                 valu = {"ng": 64, "kernel": "k_grav_walk<NEWTON>",
-                        "SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"]["mean"],
+                        "SQ_INSTS_VALU_per_launch": per_launch,
+                        "launches_averaged": len(timed),
                         "element_visits_per_launch": steps,
-                        "valu_insts_per_wave_step": c["SQ_INSTS_VALU"]["mean"] / steps,
+                        "valu_insts_per_wave_step": per_launch / steps,
                         "hbm_bytes_per_launch": traffic["hbm_bytes_per_launch"],
                         "source": "profiles/%s_walk_pmc.json + the bench line of the same PMC pass" % tag,
                         "note": "SQ_INSTS_VALU counts wave-instructions; a full-rate 64-bit VALU "
@@ -111,6 +122,27 @@ def main():
         json.dump(valu, open(os.path.join(here, "%s_walk_valu.json" % tag), "w"), indent=1)
         print(json.dumps(valu, indent=1))
     print(json.dumps(derived, indent=1))
+    # Agreement of the bench line's roofline.kernel_ms (HIP events) with the kernel trace of the SAME
+    # run: the stats summary averages over every launch of the command (Barnes-Hut pass, warm-up, the
+    # kernel alone, the drop-in legs); here only the launches of the timed steps are taken.
+    tr = os.path.join(src, "stats", "bench_kernel_trace.csv")
+    bl = os.path.join(src, "bench_under_profiler.json")
+    if os.path.exists(tr) and os.path.exists(bl):
+        rec = json.loads(open(bl).read().strip().splitlines()[-1])
+        first, k = 2 + int(rec["warmup"]), int(rec["steps"])
+        agree = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d "
+                            "--no-cpu-baseline" % (k, rec["warmup"]),
+                 "bench_ms_per_step": rec["ms_per_step"]}
+        for label, key in (("k_grav_walk<NEWTON>", "grav"), ("k_grav_walk<EWALD>", "ewald")):
+            rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
+                          for r in csv.DictReader(open(tr)) if r["Kernel_Name"].startswith(KERNELS[label]))
+            timed = rows[first:first + k]
+            ms = sum(e - b for b, e in timed) / len(timed) / 1e6
+            agree[label] = {"trace_mean_ms_of_the_timed_launches": ms,
+                            "bench_line_phase_ms": rec["phases_ms_rank0"][key],
+                            "ratio": ms / rec["phases_ms_rank0"][key]}
+        json.dump(agree, open(os.path.join(here, "%s_trace_vs_bench.json" % tag), "w"), indent=1)
+        print(json.dumps(agree, indent=1))
 
 
 main()
