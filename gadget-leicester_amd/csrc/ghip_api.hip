@@ -337,6 +337,10 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
   if(ctx->ev_ready)
     for(int i = 0; i < 16; i++)
       (void) hipEventDestroy(ctx->ev[i]);
+  if(ctx->pc_ready)
+    for(int i = 0; i < 4; i++)
+      for(int j = 0; j < 4; j++)
+        (void) hipEventDestroy(ctx->pc_ev[i][j]);
   if(ctx->ev_side)
     (void) hipEventDestroy(ctx->ev_side);
   if(ctx->ev_sizes)

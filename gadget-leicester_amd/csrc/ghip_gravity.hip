@@ -541,9 +541,13 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
   // the visit made the Newtonian wavefronts quicker (same build, c2: 8.59 ms with 8 KB -- the Ewald
   // walk then ends after the Newtonian one and hydro after both -- 8.43 with 10 KB; the LDS
   // allocation granularity leaves nothing in between).
-  static int lds_n = -1;
-  if(lds_n < 0)
-    lds_n = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 10240;
+  // (which of the two suits depends on the workload: at c2 10 KB balances the pair, at c4's size 8 KB
+  // does -- 75.6 against 80.3 ms per step; the choice follows the measured durations of the last pair
+  // that ran under the cap in use: pair_balance below.  GHIP_PAIR_NEWTON_LDS fixes it.)
+  static int lds_env = -1;
+  if(lds_env < 0)
+    lds_env = getenv("GHIP_PAIR_NEWTON_LDS") ? atoi(getenv("GHIP_PAIR_NEWTON_LDS")) : 0;
+  const int lds_n = lds_env > 0 ? lds_env : ctx->pair_lds;
   // (only when the launch is large enough to fill the chip by itself: a small share of a
   // multi-GPU run leaves room anyway -- measured on c2's shards: 2048 buckets (4 shards) 4.0 -> 3.7 ms
   // with the cap, 1024 buckets (8 shards) 2.38 -> 2.45 ms)
@@ -662,6 +666,59 @@ static int combine_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt,
   return GHIP_OK;
 }
 
+// How many Newtonian wavefronts a pair admits per SIMD (the dynamic-LDS cap of launch_walk): 8 KB = 5
+// per SIMD or 10 KB = 4 per SIMD -- the allocation granularity leaves nothing in between.  Which one
+// is better depends on the workload, so it is measured: every pair records its walks' start / end
+// events together with the setting it ran under; finished pairs are read back here (never waited
+// for) and cost max(Newtonian, 1.1 x Ewald) -- the hydro kernel, about a tenth of the Ewald walk,
+// can only start when the Ewald walk drains.  The cheaper setting is used; the other one is tried
+// again for one measurement every 64 pairs.  Scheduling only: the sums of a launch do not depend on it.
+static int pair_balance(ghip_ctx *ctx)
+{
+  if(!ctx->pc_ready)
+    {
+      for(int i = 0; i < 4; i++)
+        for(int j = 0; j < 4; j++)
+          HIPCHK(hipEventCreate(&ctx->pc_ev[i][j]));
+      ctx->pc_ready = true;
+      return GHIP_OK;
+    }
+  for(int i = 0; i < 4; i++)
+    {
+      if(ctx->pc_cap[i] == 0)
+        continue;
+      hipEvent_t *e = ctx->pc_ev[i];
+      if(hipEventQuery(e[1]) != hipSuccess || hipEventQuery(e[3]) != hipSuccess)
+        {
+          (void) hipGetLastError();   // (hipErrorNotReady is not an error)
+          continue;
+        }
+      float tn = 0, te = 0;
+      if(hipEventElapsedTime(&tn, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&te, e[2], e[3]) == hipSuccess)
+        {
+          const int k = ctx->pc_cap[i] > 8192 ? 1 : 0;
+          const float c = tn > 1.1f * te ? tn : 1.1f * te;
+          ctx->pc_cost[k] = c;
+          ctx->pc_age[k] = 0;
+        }
+      else
+        (void) hipGetLastError();
+      ctx->pc_cap[i] = 0;
+    }
+  ctx->pc_age[0]++;
+  ctx->pc_age[1]++;
+  const int cur = ctx->pair_lds > 8192 ? 1 : 0, oth = cur ^ 1;
+  if(ctx->pc_cost[cur] < 0)
+    return GHIP_OK;   // nothing known about the setting in use yet: keep it
+  int want = cur;
+  if(ctx->pc_cost[oth] < 0 || ctx->pc_age[oth] > 64)
+    want = oth;       // (stays there until a pair under it has been measured)
+  else if(ctx->pc_cost[oth] < ctx->pc_cost[cur])
+    want = oth;
+  ctx->pair_lds = want ? 10240 : 8192;
+  return GHIP_OK;
+}
+
 int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
 {
   if(!ctx->gt.built)
@@ -726,13 +783,21 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   HIPCHK(hipEventRecord(ctx->evx[0], st));
   HIPCHK(hipStreamWaitEvent(sN, ctx->evx[0], 0));
   HIPCHK(hipStreamWaitEvent(sE, ctx->evx[0], 0));
+  GCHK(pair_balance(ctx));
+  hipEvent_t *pc = ctx->pc_ev[ctx->pc_head];
+  ctx->pc_cap[ctx->pc_head] = ctx->pair_lds;
+  ctx->pc_head = (ctx->pc_head + 1) & 3;
+  HIPCHK(hipEventRecord(pc[0], sN));
   GCHK(run_walk(ctx, A, nt, tgt, sN));
+  HIPCHK(hipEventRecord(pc[1], sN));
   // (the word the hydro kernel's start waits for, see k_grav_walk: a stale 1 from the previous pair
   // would only let hydro start early, never hold it back)
   unsigned int *started = reinterpret_cast<unsigned int *>(P<unsigned long long>(ctx->counters) + 20);
   HIPCHK(hipMemsetAsync(started, 0, 4, sE));
   E.plan.started = started;
+  HIPCHK(hipEventRecord(pc[2], sE));
   GCHK(run_walk(ctx, E, nt, tgt, sE));
+  HIPCHK(hipEventRecord(pc[3], sE));
   HIPCHK(hipEventRecord(ctx->evx[3], sE));   // the Ewald walk's wavefront slots are free from here on
   if(A.k.debug_steps || E.k.debug_steps || getenv("GHIP_PAIR_TWO_COMBINES"))
     {

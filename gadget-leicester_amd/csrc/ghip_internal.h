@@ -347,6 +347,15 @@ struct ghip_ctx
   std::vector<GravCall> grav_log;  // gravity calls since the last tree build
   std::vector<void *> host_pins;   // ranges page-locked by ghip_pin_host
   bool hydro_early = false;        // ghip_set_hydro_release
+  // balance of a Newton + Ewald pair (ghip_gravity.hip, pair_balance): dynamic LDS per Newtonian
+  // workgroup in use, and a ring of the last pairs' start / end events with the cap they ran under
+  int pair_lds = 10240;
+  hipEvent_t pc_ev[4][4] = {};
+  int pc_cap[4] = {0, 0, 0, 0};        // 0: slot empty or already read
+  int pc_head = 0;
+  bool pc_ready = false;
+  float pc_cost[2] = {-1.f, -1.f};     // last measured cost of a pair under 8 KB / 10 KB
+  int pc_age[2] = {0, 0};              // pairs launched since that measurement
   hipEvent_t ev_side = nullptr;    // end of ghip_gravity_to_records' work on the pair's stream
 
   // ---- run statistics without a host synchronisation per step (ghip_run_begin / ghip_step_begin /

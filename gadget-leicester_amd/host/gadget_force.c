@@ -1687,20 +1687,22 @@ static int bh_swallow_batch(int n, const int *idx)
   int rc = ghip_blackhole_swallow(Ctx, &b, n, idx, id, bhm, am, ab, ad, mom, counts);
   if(rc == GHIP_OK)
     {
-      /* blackhole.c:1337-1345 (mode 0): the sums ADD to what the sink's record holds */
+      /* blackhole.c:1326-1333 (mode 0): the sums are ASSIGNED, in this order -- in the reference's
+       * struct BH_accreted_BHMass and BH_accreted_DustMass share the union b5 (allvars.h:1261-1267),
+       * so with both offsets equal the dust mass is what the record holds afterwards, as there */
       for(int k = 0; k < n; k++)
         {
           const int i = idx[k];
           *PF64(i, BhLay.p_bh_mass) = bhm[k];   /* (0 for a sink that was itself swallowed, :1312) */
           if(BhLay.p_bh_accreted_mass >= 0)
-            *PF64(i, BhLay.p_bh_accreted_mass) += am[k];
+            *PF64(i, BhLay.p_bh_accreted_mass) = am[k];
           if(BhLay.p_bh_accreted_bhmass >= 0)
-            *PF64(i, BhLay.p_bh_accreted_bhmass) += ab[k];
-          if(BhLay.p_bh_accreted_dustmass >= 0)
-            *PF64(i, BhLay.p_bh_accreted_dustmass) += ad[k];
+            *PF64(i, BhLay.p_bh_accreted_bhmass) = ab[k];
+          if(BhLay.p_bh_accreted_dustmass >= 0 && Cfg.dust)
+            *PF64(i, BhLay.p_bh_accreted_dustmass) = ad[k];
           if(BhLay.p_bh_accreted_momentum >= 0)
             for(int c = 0; c < 3; c++)
-              PF64(i, BhLay.p_bh_accreted_momentum)[c] += mom[3 * (size_t) k + c];
+              PF64(i, BhLay.p_bh_accreted_momentum)[c] = mom[3 * (size_t) k + c];
         }
       N_gas_swallowed += (int) counts[0];
       N_BH_swallowed += (int) counts[1];

@@ -80,13 +80,19 @@ def test_sharded_density_and_hydro_equal_the_single_rank_sums(nshards, periodic)
                          (B.F_DHSMLFAC, "dhsmlfac"), (B.F_DIVVEL, "divvel"),
                          (B.F_CURLVEL, "curlvel"), (B.F_PRESSURE, "pressure")):
             got = S.get_field(fid)[:ng]
-            assert relerr(got, od[key][:ng]) < 1e-9, key
+            if key in ("divvel", "curlvel"):
+                # sums of terms of both signs that cancel: measured against the field's scale, not
+                # element by element (an element near zero has no relative accuracy to lose)
+                assert np.abs(got - od[key][:ng]).max() < TOL * np.abs(od[key][:ng]).max(), key
+            else:
+                assert relerr(got, od[key][:ng]) < TOL, key
         st = S.each(lambda fp: fp.stats())
         assert sum(s["dens_neighbours"] for s in st) == od["ngb_visits"]
         assert sum(s["hydro_pairs"] for s in st) == oh["npairs"]
         ha = S.get_field(B.F_HYDROACCEL)
-        assert np.abs(ha - oh["hydroaccel"][:ng]).max() < 1e-9 * np.abs(oh["hydroaccel"]).max()
-        assert relerr(S.get_field(B.F_DTENTROPY), oh["dtentropy"][:ng]) < 1e-8
+        assert np.abs(ha - oh["hydroaccel"][:ng]).max() < TOL * np.abs(oh["hydroaccel"]).max()
+        de = S.get_field(B.F_DTENTROPY)
+        assert np.abs(de - oh["dtentropy"][:ng]).max() < TOL * np.abs(oh["dtentropy"][:ng]).max()
         info = S.each(lambda fp: fp.dd_info())
         assert all(i["ghosts_imported"] > 0 for i in info)
         assert sum(i["ghosts_imported"] for i in info) == sum(i["ghosts_sent"] for i in info)
@@ -127,7 +133,7 @@ def test_smoothing_lengths_that_triple_in_one_call_reselect_their_ghosts(nshards
         oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
                      od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
         for fid, key in ((B.F_HSML, "hsml"), (B.F_NUMNGB, "numngb"), (B.F_DENSITY, "density")):
-            assert relerr(S.get_field(fid)[:ng], od[key][:ng]) < 1e-9, key
+            assert relerr(S.get_field(fid)[:ng], od[key][:ng]) < TOL, key
         st = S.each(lambda fp: fp.stats())
         assert sum(s["dens_neighbours"] for s in st) == od["ngb_visits"]
         assert max(s["dens_iterations"] for s in st) == od["iterations"]
@@ -515,12 +521,12 @@ def test_sharded_sph_variants(variant):
         T.update_hmax(full, od["hsml"], od["divvel"])
         oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
                      od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
-        assert relerr(S.get_field(B.F_DENSITY)[act], od["density"][act]) < 1e-9
-        assert relerr(S.get_field(B.F_HSML)[act], od["hsml"][act]) < 1e-9
+        assert relerr(S.get_field(B.F_DENSITY)[act], od["density"][act]) < TOL
+        assert relerr(S.get_field(B.F_HSML)[act], od["hsml"][act]) < TOL
         st = S.each(lambda fp: fp.stats())
         assert sum(s["hydro_pairs"] for s in st) == oh["npairs"]
         ha = S.get_field(B.F_HYDROACCEL)[act]
-        assert np.abs(ha - oh["hydroaccel"][act]).max() < 1e-9 * np.abs(oh["hydroaccel"][act]).max()
+        assert np.abs(ha - oh["hydroaccel"][act]).max() < TOL * np.abs(oh["hydroaccel"][act]).max()
     finally:
         S.close()
 
