@@ -948,6 +948,8 @@ int density_isactive(int n)
  * around the target (:358-377, 522-545).  Their smoothing lengths live in P[] (PPP == P in such a
  * build, allvars.h:266-270): with the minimal records of this header there is nowhere to put them,
  * and the call is refused loudly rather than leaving PPP[].Hsml stale. */
+static int dd_collective(int op, const void *params, int walk, const char *what);
+
 static int density_of_sinks(const ghip_dens_params *d)
 {
   if(!Cfg.black_holes && !Cfg.dust)
@@ -961,8 +963,17 @@ static int density_of_sinks(const ghip_dens_params *d)
       for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
         if(p_type(i) == type && density_isactive(i))
           n++;
-      if(n == 0)
+      /* on ranks the pass is a collective (every rank evaluates ALL ranks' sinks against its own gas,
+       * ghip_dd_sink_args): entered by everybody, with or without sinks of its own */
+      if(n == 0 && NTask == 1)
         continue;
+      if(Lay.p_hsml < 0 && NTask > 1 && n == 0)
+        {
+          /* (a rank without such targets cannot know whether another one has them: with records that
+           * cannot hold the result nobody may have them -- the ranks that do stop below, this one
+           * must not wait in a collective for them) */
+          continue;
+        }
       if(Lay.p_hsml < 0)
         {
           snprintf(ErrBuf, sizeof(ErrBuf),
@@ -973,28 +984,56 @@ static int density_of_sinks(const ghip_dens_params *d)
           endrun(90007);
           return -1;
         }
-      int *idx = (int *) malloc((size_t) n * sizeof(int));
-      double *buf = (double *) malloc((size_t) n * 7 * sizeof(double));
-      if(!idx || !buf)
+      int *idx = (int *) malloc((size_t) (n + 1) * sizeof(int));
+      double *buf = (double *) malloc((size_t) (n + 1) * 7 * sizeof(double));
+      unsigned int *ids = (unsigned int *) malloc((size_t) (n + 1) * sizeof(unsigned int));
+      if(!idx || !buf || !ids)
         {
           free(idx);
           free(buf);
+          free(ids);
           endrun(90003);
           return -1;
         }
-      double *hs = buf, *nn = buf + n, *rho = buf + 2 * (size_t) n, *ent = buf + 3 * (size_t) n,
-             *vel = buf + 4 * (size_t) n;
+      const size_t m = (size_t) n + 1;
+      double *hs = buf, *nn = buf + m, *rho = buf + 2 * m, *ent = buf + 3 * m, *vel = buf + 4 * m;
       int k = 0;
       for(int i = FirstActiveParticle; i >= 0; i = NextActiveParticle[i])
         if(p_type(i) == type && density_isactive(i))
           {
             idx[k] = i;
             hs[k] = *ppp_hsml(i);
+            ids[k] = BhLay.p_id >= 0 ? *(unsigned int *) (prec(i) + BhLay.p_id) : (unsigned int) i;
             k++;
           }
       int iter = 0;
-      int rc = ghip_sink_density(Ctx, d, type == 5 ? All.BlackHoleNgbFactor : 1.0, n, idx, hs, nn, rho,
-                                 ent, vel, &iter);
+      int rc;
+      if(NTask > 1)
+        {
+          ghip_dd_sink_args a;
+          memset(&a, 0, sizeof(a));
+          a.dens = d;
+          a.ngb_factor = type == 5 ? All.BlackHoleNgbFactor : 1.0;
+          a.nsink = n;
+          a.sink_idx = idx;
+          a.sink_id = ids;
+          a.hsml = hs;
+          a.numngb = nn;
+          a.bh_density = rho;
+          a.bh_entropy = ent;
+          a.bh_gasvel = vel;
+          rc = dd_collective(GHIP_DD_SINK_DENSITY, &a, 0, "density of sinks (ranks)") ? GHIP_EDEVICE : GHIP_OK;
+          if(rc != GHIP_OK)
+            {
+              free(idx);
+              free(buf);
+              free(ids);
+              return -1;
+            }
+        }
+      else
+        rc = ghip_sink_density(Ctx, d, type == 5 ? All.BlackHoleNgbFactor : 1.0, n, idx, hs, nn, rho, ent,
+                               vel, &iter);
       if(rc == GHIP_OK)
         {
           const int o_rho = type == 5 ? BhLay.p_bh_density : BhLay.p_dust_density;
@@ -1016,6 +1055,7 @@ static int density_of_sinks(const ghip_dens_params *d)
         }
       free(idx);
       free(buf);
+      free(ids);
       if(chk(rc, "ghip_sink_density"))
         return -1;
     }
@@ -1585,6 +1625,20 @@ static int bh_ready(const char *who)
       endrun(90002);
       return -1;
     }
+  if(NTask > 1)
+    {
+      /* the passes are collectives on the trees gravity_tree() and density() of THIS step left on the
+       * device (blackhole_accretion follows them in compute_accelerations / run.c) */
+      if(!DeviceFresh || !DdReady)
+        {
+          snprintf(ErrBuf, sizeof(ErrBuf), "%s on %d ranks must follow gravity_tree() and density() of the "
+                   "same step", who, NTask);
+          fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+          endrun(90002);
+          return -1;
+        }
+      return 0;
+    }
   return ensure_tree();
 }
 
@@ -1639,8 +1693,8 @@ static int bh_marks_to_records(int with_mass)
 /* blackhole_evaluate / _swallow of the sinks idx[0, n): results into the records */
 static int bh_evaluate_batch(int n, const int *idx)
 {
-  unsigned int *id = (unsigned int *) malloc((size_t) n * sizeof(unsigned int));
-  double *md = (double *) malloc((size_t) n * 2 * sizeof(double));
+  unsigned int *id = (unsigned int *) malloc((size_t) (n + 1) * sizeof(unsigned int));
+  double *md = (double *) malloc((size_t) (n + 1) * 2 * sizeof(double));
   if(!id || !md)
     {
       free(id);
@@ -1657,7 +1711,24 @@ static int bh_evaluate_batch(int n, const int *idx)
     }
   ghip_bh_params b;
   fill_bh_params(&b);
-  int rc = ghip_blackhole_evaluate(Ctx, &b, n, idx, id, md, rho);
+  int rc;
+  if(NTask > 1)
+    {
+      /* every rank's sinks against every rank's particles (blackhole.c:310-470's export, turned round) */
+      ghip_dd_sink_args a;
+      memset(&a, 0, sizeof(a));
+      a.bh = &b;
+      a.nsink = n;
+      a.sink_idx = idx;
+      a.sink_id = id;
+      a.bh_mdot = md;
+      a.bh_density_in = rho;
+      rc = dd_collective(GHIP_DD_BH_EVALUATE, &a, 0, "blackhole_evaluate (ranks)") ? GHIP_EDEVICE : GHIP_OK;
+      free(id);
+      free(md);
+      return rc == GHIP_OK ? 0 : -1;
+    }
+  rc = ghip_blackhole_evaluate(Ctx, &b, n, idx, id, md, rho);
   free(id);
   free(md);
   return chk(rc, "ghip_blackhole_evaluate") ? -1 : 0;
@@ -1665,8 +1736,8 @@ static int bh_evaluate_batch(int n, const int *idx)
 
 static int bh_swallow_batch(int n, const int *idx)
 {
-  unsigned int *id = (unsigned int *) malloc((size_t) n * sizeof(unsigned int));
-  double *buf = (double *) malloc((size_t) n * 7 * sizeof(double));
+  unsigned int *id = (unsigned int *) malloc((size_t) (n + 1) * sizeof(unsigned int));
+  double *buf = (double *) malloc((size_t) (n + 1) * 7 * sizeof(double));
   if(!id || !buf)
     {
       free(id);
@@ -1674,8 +1745,8 @@ static int bh_swallow_batch(int n, const int *idx)
       endrun(90003);
       return -1;
     }
-  double *bhm = buf, *am = buf + n, *ab = buf + 2 * (size_t) n, *ad = buf + 3 * (size_t) n,
-         *mom = buf + 4 * (size_t) n;
+  const size_t m = (size_t) n + 1;
+  double *bhm = buf, *am = buf + m, *ab = buf + 2 * m, *ad = buf + 3 * m, *mom = buf + 4 * m;
   for(int k = 0; k < n; k++)
     {
       id[k] = *(unsigned int *) (prec(idx[k]) + BhLay.p_id);
@@ -1684,7 +1755,31 @@ static int bh_swallow_batch(int n, const int *idx)
   ghip_bh_params b;
   fill_bh_params(&b);
   long long counts[3] = { 0, 0, 0 };
-  int rc = ghip_blackhole_swallow(Ctx, &b, n, idx, id, bhm, am, ab, ad, mom, counts);
+  int rc;
+  if(NTask > 1)
+    {
+      ghip_dd_sink_args a;
+      memset(&a, 0, sizeof(a));
+      a.bh = &b;
+      a.nsink = n;
+      a.sink_idx = idx;
+      a.sink_id = id;
+      a.sink_bh_mass = bhm;
+      a.acc_mass = am;
+      a.acc_bhmass = ab;
+      a.acc_dustmass = ad;
+      a.acc_momentum = mom;
+      a.counts = counts;   /* victims swallowed ON THIS RANK, as the reference counts them (:1296-1309) */
+      rc = dd_collective(GHIP_DD_BH_SWALLOW, &a, 0, "blackhole_evaluate_swallow (ranks)") ? GHIP_EDEVICE : GHIP_OK;
+      if(rc != GHIP_OK)
+        {
+          free(id);
+          free(buf);
+          return -1;
+        }
+    }
+  else
+    rc = ghip_blackhole_swallow(Ctx, &b, n, idx, id, bhm, am, ab, ad, mom, counts);
   if(rc == GHIP_OK)
     {
       /* blackhole.c:1326-1333 (mode 0): the sums are ASSIGNED, in this order -- in the reference's
@@ -1720,8 +1815,9 @@ int blackhole_evaluate(int target, int mode, int *nexport, int *nsend_local)
   (void) nsend_local;
   if(bh_ready("blackhole_evaluate"))
     return -1;
-  if(mode != 0 || target < 0 || target >= NumPart)
+  if(mode != 0 || target < 0 || target >= NumPart || NTask > 1)
     {
+      /* (on ranks the pass is a collective over ALL ranks' sinks: blackhole_accretion_neighbour_passes) */
       endrun(90002);
       return -1;
     }
@@ -1737,8 +1833,9 @@ int blackhole_evaluate_swallow(int target, int mode, int *nexport, int *nsend_lo
   (void) nsend_local;
   if(bh_ready("blackhole_evaluate_swallow"))
     return -1;
-  if(mode != 0 || target < 0 || target >= NumPart)
+  if(mode != 0 || target < 0 || target >= NumPart || NTask > 1)
     {
+      /* (on ranks the pass is a collective over ALL ranks' sinks: blackhole_accretion_neighbour_passes) */
       endrun(90002);
       return -1;
     }
@@ -1762,9 +1859,9 @@ void blackhole_accretion_neighbour_passes(void)
    * run.c / blackhole.c; Injected_BH_Energy accumulates until cooling consumes it) */
   if(bh_marks_to_device())
     return;
-  if(n > 0)
+  if(n > 0 || NTask > 1)   /* (ranks: a collective, entered with or without sinks of one's own) */
     {
-      int *idx = (int *) malloc((size_t) n * sizeof(int));
+      int *idx = (int *) malloc((size_t) (n + 1) * sizeof(int));
       if(!idx)
         {
           endrun(90003);
@@ -1961,7 +2058,9 @@ static void density_ranks(void)
     return;
   if(chk(ghip_download_aos(Ctx, records_p(), records_s(), &Lay, 0, 1, 0), "ghip_download_aos"))
     return;
-  /* (sink / dust density targets on ranks: GHIP_DD_SINK_DENSITY, through the ghip_dd_* interface) */
+  /* Type-5 / Type-2 targets: every rank's sinks against every rank's gas (GHIP_DD_SINK_DENSITY) */
+  if(density_of_sinks(&d))
+    return;
   Phase = 2;
   CPU_Step_Density += wallclock() - t0;
 }

@@ -68,10 +68,13 @@ def main():
                 th.append(1e3 * (time.perf_counter() - t0))
             h = run_op(S, B.DD_HYDRO, pr.g_hydro())
             S.each(lambda fp: fp.gravity_finish(pr.G))
-        names = (["mig%d" % i for i in range(len(mig))] + ["grav:localtree+groups", "grav:let-select",
-                                                            "grav:merged-tree+walks"] +
-                 ["dens:groups", "dens:ghost-select", "dens:gastree+iter", "dens:refresh"] +
-                 ["hmax", "hydro"])
+        def label(base, known, k):
+            return [known[i] if i < len(known) else "%s:phase%d" % (base, i) for i in range(k)]
+        names = (["mig%d" % i for i in range(len(mig))] +
+                 label("grav", ["grav:localtree+groups", "grav:let-select", "grav:merged-tree+walks"], len(g)) +
+                 label("dens", ["dens:groups", "dens:ghost-select", "dens:gastree+iter",
+                                "dens:growth-check+refresh-pack", "dens:refresh-unpack"], len(d)) +
+                 ["hmax"] + label("hydro", ["hydro"], len(h)))
         rows = mig + g + d + [th] + h
         tot = sum(max(r) for r in rows)
         info = S.each(lambda fp: fp.dd_info())

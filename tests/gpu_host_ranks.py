@@ -5,9 +5,11 @@ Every rank builds the same seeded problem, keeps the particles of its Peano-Hilb
 536 / 264-byte records (the shipped bundle's layout, bound by byte offsets), describes the
 decomposition the way domain_Decomposition leaves it (TopNodes[] leaves in key order,
 DomainStartList / DomainEndList per rank) and calls accel.c's sequence through the reference-named
-symbols of libgadget_force.so with NTask = world size: gravity_tree() x 2, density(),
-force_update_hmax(), hydro_force().  Exchanges go through the host's all-gather (gloo).  Rank 0
-gathers the records and checks them against the oracle's single global tree; prints one JSON line."""
+symbols of libgadget_force.so with NTask = world size: gravity_tree() x 2, density() -- gas, sinks
+and dust grains --, force_update_hmax(), hydro_force(), then the neighbour passes of
+blackhole_accretion().  Exchanges go through the host's all-gather (gloo).  Rank 0 gathers the
+records and checks them against the oracle's single global tree; prints one JSON line."""
+import ctypes as C
 import importlib
 import json
 import os
@@ -36,6 +38,7 @@ def main():
     sp = SinkProblem(ng=12, periodic=1, nsink=5, ndust=100)
     pr = sp.pr
     n, ng = pr.n, pr.ngas
+    sp.hsml[sp.dust] = 2.0 * pr.ic["spacing"]      # a first guess for the grains' smoothing lengths
     eps = pr.force_soft[0] / 2.8
 
     # the decomposition: a histogram of the keys over the cells of one level, cut by
@@ -63,7 +66,9 @@ def main():
 
     lay, bh = TB.bundle_layouts(B, H)
     P, Sp = TB.bundle_records(sp, gid)
-    host = H.Host(periodic=1, rank=rank, nranks=world)
+    host = H.Host(periodic=1, black_holes=1, dust=1, accretion_of_dust_only=1, accretion_density=1,
+                  rank=rank, nranks=world)
+    swallowed = [0, 0, 0]
 
     def allgather(data):
         t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
@@ -85,6 +90,9 @@ def main():
         L.density()
         L.force_update_hmax()
         L.hydro_force()
+        L.blackhole_accretion_neighbour_passes()
+        swallowed = [C.c_int.in_dll(L, k).value
+                     for k in ("N_gas_swallowed", "N_BH_swallowed", "N_dust_swallowed")]
         if host.endrun_codes:
             ok, err = False, "endrun %r: %s" % (host.endrun_codes, L.gadget_force_last_error().decode())
     except Exception as e:   # noqa: BLE001
@@ -92,7 +100,7 @@ def main():
 
     # gather the records on rank 0
     blob = [None] * world
-    dist.all_gather_object(blob, (ok, err, gid, P.tobytes(), Sp.tobytes()))
+    dist.all_gather_object(blob, (ok, err, gid, P.tobytes(), Sp.tobytes(), swallowed))
     out = None
     if rank == 0:
         ok = all(b[0] for b in blob)
@@ -102,7 +110,9 @@ def main():
             Pg = np.zeros(n, TB.P536)
             Sg = np.zeros(ng, TB.S264)
             seen = 0
-            for _ok, _e, g, pb, sb in blob:
+            counts = np.zeros(3, np.int64)
+            for _ok, _e, g, pb, sb, sw in blob:
+                counts += np.asarray(sw, np.int64)
                 Pr = np.frombuffer(pb, TB.P536)
                 Sr = np.frombuffer(sb, TB.S264)
                 Pg[g] = Pr
@@ -130,6 +140,34 @@ def main():
                          od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
             out["rel_hydro"] = float(np.abs(Sg["HydroAccel"] - oh["hydroaccel"][:ng]).max() /
                                      np.abs(oh["hydroaccel"]).max())
+            # density() of the Type-5 / Type-2 targets: every rank's sinks against every rank's gas
+            osk = O.sink_density(T, pr.o_dens(), 1.5, sp.sinks, pr.velpred, pr.entropy, sp.hsml)
+            dust = sp.dust.astype(np.int32)
+            odu = O.sink_density(T, pr.o_dens(), 1.0, dust, pr.velpred, pr.entropy, sp.hsml)
+            out["rel_sink_density"] = float(max(relerr(Pg["Hsml"][sp.sinks], osk["hsml"][sp.sinks]),
+                                                relerr(Pg["BH_Density"][sp.sinks], osk["density"]),
+                                                relerr(Pg["BH_Entropy"][sp.sinks], osk["entropy"]),
+                                                relerr(Pg["Hsml"][dust], odu["hsml"][dust]),
+                                                relerr(Pg["DUST_Density"][dust], odu["density"])))
+            # the neighbour passes of blackhole_accretion(): marks, feedback, swallowed mass
+            hs = od["hsml"].copy()
+            hs[sp.sinks], hs[dust] = osk["hsml"][sp.sinks], odu["hsml"][dust]
+            op = sp.params(O.BhParams, accretion_of_dust_only=1, accretion_density=1, CritDensity=1.0,
+                           SofteningBndry=eps)
+            T2 = O.Tree(pr.ic["pos"], pr.ic["vel"], pr.ic["mass"].copy(), pr.ic["type"], pr.force_soft,
+                        hsml=hs, extent=pr.extent)
+            osw, oinj = O.blackhole_evaluate(T2, op, sp.sinks, sp.ids, hs, pr.timebin, sp.mdot, osk["density"],
+                                             od["density"][:ng], np.zeros(n, np.uint32), np.zeros(ng))
+            oo = O.blackhole_swallow(T2, op, sp.sinks, sp.ids, hs, osw, sp.bh_mass)
+            out["marks_equal"] = bool(np.array_equal(Pg["SwallowID"], osw))
+            out["victims"] = int((osw > 0).sum())
+            out["rel_injected"] = float(np.abs(Sg["Injected_BH_Energy"] - oinj).max() /
+                                        max(np.abs(oinj).max(), 1e-300))
+            out["rel_accreted"] = float(np.abs(Pg["BH_accreted_Mass"][sp.sinks] - oo["acc_mass"]).max() /
+                                        max(np.abs(oo["acc_mass"]).max(), 1e-300))
+            out["masses_equal"] = bool(np.array_equal(Pg["Mass"], T2.mass))
+            out["swallow_counts"] = [int(v) for v in counts]
+            out["swallow_counts_oracle"] = [int(v) for v in oo["counts"]]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     host.close()
     dist.barrier()

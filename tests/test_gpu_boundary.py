@@ -222,8 +222,9 @@ def test_four_call_sequence_on_two_ranks_through_the_reference_named_symbols():
     """accel.c's sequence with NTask = 2: one process per rank (as the reference's MPI ranks), both on
     this box's one GPU, each with its 536-byte records, the ranks' key ranges out of TopNodes /
     DomainStartList, exchanges through the host's all-gather (gloo here, MPI_Allgather in a host).
-    tests/gpu_host_ranks.py is the rank program; rank 0 checks the gathered records against the
-    oracle's single global tree."""
+    tests/gpu_host_ranks.py is the rank program (BLACK_HOLES + DUST configuration: density() also serves
+    the Type-5 / Type-2 targets, and blackhole_accretion's neighbour passes follow); rank 0 checks the
+    gathered records against the oracle's single global tree."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -239,4 +240,10 @@ def test_four_call_sequence_on_two_ranks_through_the_reference_named_symbols():
     out = json.loads(lines[0])
     assert out["ok"], out
     assert out["counts_equal"] and out["rel_acc"] < TOL and out["rel_density"] < TOL
-    assert out["rel_hydro"] < 1e-9 and out["particles"] == out["particles_expected"]
+    assert out["rel_hydro"] < TOL and out["particles"] == out["particles_expected"]
+    # density() of the sinks and dust grains, and the neighbour passes of blackhole_accretion(), as
+    # collectives: every rank's sinks meet every rank's particles
+    assert out["rel_sink_density"] < 1e-12
+    assert out["marks_equal"] and out["victims"] > 3 and out["masses_equal"]
+    assert out["rel_injected"] < 1e-12 and out["rel_accreted"] < 1e-13
+    assert out["swallow_counts"] == out["swallow_counts_oracle"]
