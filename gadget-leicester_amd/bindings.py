@@ -184,6 +184,7 @@ EXPORTS = [
     "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
     "ghip_gravity_vacuum_energy", "ghip_pm_kick",
     "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
+    "ghip_set_dynamic_tree", "ghip_tree_substep", "ghip_tree_kick_nodes", "ghip_tree_dump_dynamic",
     "ghip_gas_block_mixed", "ghip_set_hydro_release", "ghip_download_aos_async",
     "ghip_gravity_to_records", "ghip_pin_host", "ghip_unpin_host", "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
@@ -237,6 +238,10 @@ def lib():
         L.ghip_morton_keys.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]
         L.ghip_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ghip_tree_dump.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, vp]
+        L.ghip_set_dynamic_tree.argtypes = [vp, C.c_int]
+        L.ghip_tree_substep.argtypes = [vp, C.c_double]
+        L.ghip_tree_kick_nodes.argtypes = [vp, C.c_int, vp, vp]
+        L.ghip_tree_dump_dynamic.argtypes = [vp, C.POINTER(C.c_int), vp, vp, vp, vp]
         L.ghip_stream.argtypes = [vp]
         L.ghip_stream.restype = vp
         L.ghip_sync.argtypes = [vp]
@@ -590,6 +595,30 @@ class ForcePath:
         self._chk(self.L.ghip_tree_dump(self.h, which, C.byref(n2), _ptr(out["xm"]),
                                         _ptr(out["cl"]), _ptr(out["lk"]), _ptr(out["aux"]),
                                         _ptr(out["perm"])))
+        return out
+
+    # ---- sub-steps on the tree of the last full build (forcetree.c:1356-1651) ----
+    def set_dynamic_tree(self, on=True):
+        self._chk(self.L.ghip_set_dynamic_tree(self.h, int(bool(on))))
+
+    def tree_substep(self, dt_drift):
+        self._chk(self.L.ghip_tree_substep(self.h, float(dt_drift)))
+
+    def tree_kick_nodes(self, idx, dv):
+        idx = np.ascontiguousarray(idx, np.int32)
+        dv = np.ascontiguousarray(dv, np.float64)
+        assert dv.shape == (len(idx), 3)
+        self._chk(self.L.ghip_tree_kick_nodes(self.h, len(idx), _ptr(idx), _ptr(dv)))
+
+    def tree_dump_dynamic(self):
+        ne = C.c_int(0)
+        self._chk(self.L.ghip_tree_dump_dynamic(self.h, C.byref(ne), None, None, None, None))
+        ne = ne.value
+        out = dict(xm=np.zeros((ne, 4)), cl=np.zeros((ne, 4)), ev=np.zeros((ne, 4)),
+                   lk=np.zeros((ne, 4), np.int32))
+        n2 = C.c_int(0)
+        self._chk(self.L.ghip_tree_dump_dynamic(self.h, C.byref(n2), _ptr(out["xm"]), _ptr(out["cl"]),
+                                                _ptr(out["ev"]), _ptr(out["lk"])))
         return out
 
     def sync(self):

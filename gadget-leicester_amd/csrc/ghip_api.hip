@@ -324,6 +324,7 @@ extern "C" void ghip_destroy(ghip_ctx *ctx)
     free_buf(*b);
   free_tree(ctx->gt);
   free_tree(ctx->st);
+  ghip_dyn_release(ctx);
   ghip_dd_release(ctx);
   ghip_pm_release(ctx);
   free_buf(ctx->pm_rho);
@@ -1101,7 +1102,12 @@ extern "C" int ghip_tree_build(ghip_ctx *ctx, const double corner[3], const doub
   ctx->dlen = len;
   for(int j = 0; j < 6; j++)
     ctx->soft[j] = soft[j];
-  return ghip_tree_build_impl(ctx);
+  ctx->dyn_use = false;
+  GCHK(ghip_tree_build_impl(ctx));
+  // a full build (TreeReconstructFlag): with ghip_set_dynamic_tree the tree sub-steps will drift
+  if(ctx->dyn_on)
+    GCHK(ghip_dyn_capture(ctx));
+  return GHIP_OK;
 }
 
 extern "C" int ghip_set_adaptive_gravsoft(ghip_ctx *ctx, int on)

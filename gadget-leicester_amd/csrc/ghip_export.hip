@@ -253,3 +253,317 @@ extern "C" int ghip_tree_export(ghip_ctx *ctx, const ghip_node_layout *lay, int 
   HIPCHK(ghip_stream_sync(ctx, st));
   return GHIP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// The gravity tree between two full builds ("dynamic tree update", forcetree.c:1356-1520).
+//
+// On a sub-step the reference does not rebuild its tree: nodes keep the cells of the last build,
+// their centres of mass move with the mass-weighted velocity vs, their side length grows by
+// 2 vmax dt so that the cell still covers its particles, and the momentum the kicked particles gained
+// is folded into vs at the next drift.  Interaction sets on such a tree differ from those on a tree
+// of the current positions, so a host that wants the reference's sub-step forces needs THIS tree.
+// Kept here as a second element list (ctx->dyn): a copy of the gravity tree of the last
+// ghip_tree_build with (vs, vmax) and the pending kicks per node.  ghip_tree_substep rebuilds the
+// tree of the current positions as ever (target order, the gas tree and everything SPH derive from
+// it; neighbour sets are geometric and do not depend on which tree finds them) and brings the kept
+// tree to the current time; the gravity walks then read the kept tree's records.
+// The reference drifts a node when a walk or a kick first meets it; here all nodes move at once, which
+// gives the same state up to the rounding of s += vs dt in one piece or in several.
+// ---------------------------------------------------------------------------------------------
+static int dyn_copy(ghip_ctx *ctx, DevBuf &dst, const DevBuf &src, size_t bytes)
+{
+  GCHK(ghip_ensure(ctx, dst, bytes > 0 ? bytes : 16));
+  if(bytes > 0)
+    HIPCHK(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return GHIP_OK;
+}
+
+int ghip_dyn_capture(ghip_ctx *ctx)
+{
+  TreeDev &g = ctx->gt, &d = ctx->dyn;
+  ctx->dyn_valid = false;
+  ctx->dyn_use = false;
+  if(!g.built || g.n == 0)
+    return GHIP_OK;
+  if(ctx->dd.on)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_dynamic_tree: not on a multi-GPU shard (the merged tree of "
+                     "a domain-decomposed run is rebuilt every call)");
+  if(ctx->adaptive_gravsoft)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_set_dynamic_tree: not with ADAPTIVE_GRAVSOFT_FORGAS (the nodes' "
+                     "maxsoft follows the smoothing lengths)");
+  GCHK(ghip_tree_verify(ctx));   // exact sizes on the host
+  hipStream_t st = ctx->stream;
+  const size_t ne = (size_t) g.nelem, n = (size_t) g.n;
+  d.n = g.n;
+  d.nnodes = g.nnodes;
+  d.nelem = g.nelem;
+  d.maxlevel = g.maxlevel;
+  d.cap_nodes = g.nnodes;
+  GCHK(dyn_copy(ctx, d.xm, g.xm, ne * sizeof(double4)));
+  GCHK(dyn_copy(ctx, d.cl, g.cl, ne * sizeof(double4)));
+  GCHK(dyn_copy(ctx, d.lk, g.lk, ne * sizeof(int4)));
+  GCHK(dyn_copy(ctx, d.aux, g.aux, (ne + 1) * sizeof(double)));
+  GCHK(dyn_copy(ctx, d.perm, g.perm, n * sizeof(int)));
+  GCHK(dyn_copy(ctx, d.dsz, g.dsz, sizeof(TreeSizes)));
+  d.hsz = g.hsz;
+  GCHK(ghip_ensure(ctx, ctx->dyn_ev, ne * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, ctx->dyn_dp, ne * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, ctx->dyn_kick, ne * sizeof(double4)));
+  GCHK(ghip_ensure(ctx, ctx->dyn_eh, ne * sizeof(double2)));
+  GCHK(ghip_ensure(ctx, ctx->dyn_cnt, ne * 4));
+  GCHK(ghip_ensure(ctx, ctx->dyn_fa, ne * 4));
+  HIPCHK(hipMemsetAsync(ctx->dyn_dp.p, 0, ne * sizeof(double4), st));
+  const int nelem = g.nelem;
+  // vs, vmax per element (force_update_node_recursive, forcetree.c:560-611, 830-846)
+  k_ext_particles<<<cdiv(nelem, 256), 256, 0, st>>>(
+    nelem, ctx->n, ctx->ngas, P<int4>(d.lk), P<int>(d.perm), P<double>(ctx->f[GHIP_F_VEL]),
+    P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_DIVVEL]),
+    P<double4>(ctx->dyn_ev), P<double2>(ctx->dyn_eh), P<int>(ctx->dyn_cnt), P<int>(ctx->dyn_fa));
+  for(int L = d.maxlevel; L >= 0; L--)
+    k_ext_level<<<cdiv(nelem, 256), 256, 0, st>>>(nelem, L, P<int4>(d.lk), P<double4>(d.xm),
+                                                  P<double4>(ctx->dyn_ev), P<double2>(ctx->dyn_eh),
+                                                  P<int>(ctx->dyn_cnt), P<int>(ctx->dyn_fa));
+  HIPCHK(hipGetLastError());
+  d.built = true;
+  GCHK(ghip_build_segments(ctx, d, true));
+  ctx->dyn_valid = true;
+  return GHIP_OK;
+}
+
+void ghip_dyn_release(ghip_ctx *ctx)
+{
+  DevBuf *bs[] = {&ctx->dyn.xm, &ctx->dyn.cl, &ctx->dyn.lk, &ctx->dyn.aux, &ctx->dyn.perm, &ctx->dyn.dsz,
+                  &ctx->dyn.seg_start, &ctx->dyn.seg_nanc, &ctx->dyn.seg_anc, &ctx->dyn.mq, &ctx->dyn.mq2,
+                  &ctx->dyn_ev, &ctx->dyn_dp, &ctx->dyn_eh, &ctx->dyn_cnt, &ctx->dyn_fa, &ctx->dyn_kick,
+                  &ctx->kick_dv, &ctx->kick_flag};
+  for(DevBuf *b : bs)
+    {
+      if(b->p)
+        (void) hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+  ctx->dyn_valid = ctx->dyn_use = false;
+}
+
+// force_kick_node (forcetree.c:1455-1520), first half: what a kicked particle hands to its ancestors --
+// (Mass dv, max_j |Vel_j| of the NEW velocity); a particle that was not kicked hands up (0, -1)
+__global__ void k_dyn_kick_particles(int nelem, int n, const int4 *__restrict__ lk,
+                                     const int *__restrict__ perm, const double *__restrict__ mass,
+                                     const double *__restrict__ vel, const double *__restrict__ dv,
+                                     const int *__restrict__ flag, double4 *__restrict__ up)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y < 0)
+    return;
+  int i = perm[me.y];
+  if(!flag[i])
+    {
+      up[e] = make_double4(0, 0, 0, -1);
+      return;
+    }
+  double m = mass[i];
+  double vmax = fmax(fabs(vel[i]), fmax(fabs(vel[(size_t) n + i]), fabs(vel[2 * (size_t) n + i])));
+  up[e] = make_double4(m * dv[i], m * dv[(size_t) n + i], m * dv[2 * (size_t) n + i], vmax);
+}
+
+// second half, level by level from the deepest: a node sums its children's contributions (list order),
+// records them in its pending dp, raises its vmax and the KICKED flag (dp.w) -- only nodes with a kicked
+// particle below are touched, like the ancestor loop of the reference
+__global__ void k_dyn_kick_level(int nelem, int level, const int4 *__restrict__ lk,
+                                 double4 *__restrict__ up, double4 *__restrict__ dp,
+                                 double4 *__restrict__ ev)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y != -(level + 1))
+    return;
+  double sx = 0, sy = 0, sz = 0, vmax = -1;
+  for(int c = e + 1; c < me.x;)
+    {
+      double4 u = up[c];
+      if(u.w >= 0)
+        {
+          sx += u.x;
+          sy += u.y;
+          sz += u.z;
+          vmax = fmax(vmax, u.w);
+        }
+      c = lk[c].x;
+    }
+  up[e] = make_double4(sx, sy, sz, vmax);
+  if(vmax >= 0)
+    {
+      double4 p = dp[e];
+      dp[e] = make_double4(p.x + sx, p.y + sy, p.z + sz, 1.0);
+      double4 v = ev[e];
+      if(v.w < vmax)
+        ev[e] = make_double4(v.x, v.y, v.z, vmax);
+    }
+}
+
+static int dyn_kick_pass(ghip_ctx *ctx, const double *dv, const int *flag)
+{
+  TreeDev &d = ctx->dyn;
+  hipStream_t st = ctx->stream;
+  const int nelem = d.nelem;
+  k_dyn_kick_particles<<<cdiv(nelem, 256), 256, 0, st>>>(
+    nelem, ctx->n, P<int4>(d.lk), P<int>(d.perm), P<double>(ctx->f[GHIP_F_MASS]),
+    P<double>(ctx->f[GHIP_F_VEL]), dv, flag, P<double4>(ctx->dyn_kick));
+  for(int L = d.maxlevel; L >= 0; L--)
+    k_dyn_kick_level<<<cdiv(nelem, 256), 256, 0, st>>>(nelem, L, P<int4>(d.lk), P<double4>(ctx->dyn_kick),
+                                                       P<double4>(ctx->dyn_dp), P<double4>(ctx->dyn_ev));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
+// what the last ghip_advance_timesteps recorded (kick_dv, kick_flag)
+int ghip_dyn_kick_recorded(ghip_ctx *ctx)
+{
+  if(!ctx->dyn_on || !ctx->dyn_valid || ctx->dyn.n != ctx->n)
+    return GHIP_OK;
+  return dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag));
+}
+
+__global__ void k_dyn_scatter_kicks(int nk, int n, const int *__restrict__ idx, const double *__restrict__ dv3,
+                                    double *__restrict__ dv, int *__restrict__ flag)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= nk)
+    return;
+  int i = idx[k];
+  if(i < 0 || i >= n)
+    return;
+  flag[i] = 1;
+  for(int j = 0; j < 3; j++)
+    dv[(size_t) j * n + i] = dv3[3 * (size_t) k + j];
+}
+
+extern "C" int ghip_tree_kick_nodes(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3)
+{
+  if(!ctx || nkicked < 0 || (nkicked > 0 && (!idx || !dv3)))
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  if(!ctx->dyn_on || !ctx->dyn_valid)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_kick_nodes: no kept tree (ghip_set_dynamic_tree, then "
+                     "ghip_tree_build)");
+  if(nkicked == 0)
+    return GHIP_OK;
+  const size_t n = (size_t) ctx->n;
+  hipStream_t st = ctx->stream;
+  GCHK(ghip_ensure(ctx, ctx->kick_dv, 3 * n * 8));
+  GCHK(ghip_ensure(ctx, ctx->kick_flag, n * 4));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nkicked * 28 + 64));
+  int *didx = P<int>(ctx->stage);
+  double *ddv = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->stage.p) + (((size_t) nkicked * 4 + 15) & ~(size_t) 15));
+  HIPCHK(hipMemcpyAsync(didx, idx, (size_t) nkicked * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ddv, dv3, (size_t) nkicked * 24, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->kick_flag.p, 0, n * 4, st));
+  k_dyn_scatter_kicks<<<cdiv(nkicked, 256), 256, 0, st>>>(nkicked, ctx->n, didx, ddv, P<double>(ctx->kick_dv),
+                                                          P<int>(ctx->kick_flag));
+  GCHK(dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag)));
+  HIPCHK(ghip_stream_sync(ctx, st));   // (idx / dv3 are the caller's)
+  return GHIP_OK;
+}
+
+// force_drift_node (forcetree.c:1356-1452) for every node, and the particles' current positions and
+// masses into the kept element list (the reference reads P[] live in its walks)
+__global__ void k_dyn_drift(int nelem, int n, const int4 *__restrict__ lk, const int *__restrict__ perm,
+                            const double *__restrict__ pos, const double *__restrict__ mass,
+                            double dt_drift, double4 *__restrict__ xm, double4 *__restrict__ cl,
+                            double4 *__restrict__ ev, double4 *__restrict__ dp)
+{
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= nelem)
+    return;
+  int4 me = lk[e];
+  if(me.y >= 0)
+    {
+      int i = perm[me.y];
+      xm[e] = make_double4(pos[i], pos[(size_t) n + i], pos[2 * (size_t) n + i], mass[i]);
+      return;
+    }
+  double4 x = xm[e], v = ev[e], p = dp[e];
+  if(p.w != 0)   // BITFLAG_NODEHASBEENKICKED: :1368-1400
+    {
+      double fac = x.w != 0 ? 1 / x.w : 0;
+      v.x += fac * p.x;
+      v.y += fac * p.y;
+      v.z += fac * p.z;
+      ev[e] = v;
+      dp[e] = make_double4(0, 0, 0, 0);
+    }
+  x.x += v.x * dt_drift;   // :1440-1441
+  x.y += v.y * dt_drift;
+  x.z += v.z * dt_drift;
+  xm[e] = x;
+  double4 c = cl[e];
+  c.w += 2 * v.w * dt_drift;   // :1442
+  cl[e] = c;
+}
+
+extern "C" int ghip_set_dynamic_tree(ghip_ctx *ctx, int on)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  ctx->dyn_on = on != 0;
+  if(!ctx->dyn_on)
+    ghip_dyn_release(ctx);
+  return GHIP_OK;
+}
+
+extern "C" int ghip_tree_substep(ghip_ctx *ctx, double dt_drift)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  if(!ctx->dyn_on || !ctx->dyn_valid)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_substep: no kept tree (ghip_set_dynamic_tree, then a full "
+                     "ghip_tree_build)");
+  if(ctx->dyn.n != ctx->n)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_substep: the particle number changed since the full build "
+                     "(%d -> %d): rebuild", ctx->dyn.n, ctx->n);
+  // the tree of the current positions: target order, the gas tree, everything SPH
+  ctx->dyn_use = false;
+  GCHK(ghip_tree_build_impl(ctx));
+  TreeDev &d = ctx->dyn;
+  k_dyn_drift<<<cdiv(d.nelem, 256), 256, 0, ctx->stream>>>(
+    d.nelem, ctx->n, P<int4>(d.lk), P<int>(d.perm), P<double>(ctx->f[GHIP_F_POS]),
+    P<double>(ctx->f[GHIP_F_MASS]), dt_drift, P<double4>(d.xm), P<double4>(d.cl), P<double4>(ctx->dyn_ev),
+    P<double4>(ctx->dyn_dp));
+  HIPCHK(hipGetLastError());
+  GCHK(ghip_fill_walk_records(ctx, d));
+  ctx->dyn_use = true;
+  return GHIP_OK;
+}
+
+// the kept tree's nodes in pre-order: s, mass, len, vs, vmax (tests)
+extern "C" int ghip_tree_dump_dynamic(ghip_ctx *ctx, int *nelem, double *xm4, double *cl4, double *ev4, int *lk4)
+{
+  if(!ctx || !nelem)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  if(!ctx->dyn_valid)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_tree_dump_dynamic: no kept tree");
+  TreeDev &d = ctx->dyn;
+  *nelem = d.nelem;
+  hipStream_t st = ctx->stream;
+  const size_t ne = (size_t) d.nelem;
+  if(xm4)
+    HIPCHK(hipMemcpyAsync(xm4, d.xm.p, ne * 32, hipMemcpyDeviceToHost, st));
+  if(cl4)
+    HIPCHK(hipMemcpyAsync(cl4, d.cl.p, ne * 32, hipMemcpyDeviceToHost, st));
+  if(ev4)
+    HIPCHK(hipMemcpyAsync(ev4, ctx->dyn_ev.p, ne * 32, hipMemcpyDeviceToHost, st));
+  if(lk4)
+    HIPCHK(hipMemcpyAsync(lk4, d.lk.p, ne * 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(ghip_stream_sync(ctx, st));
+  return GHIP_OK;
+}

@@ -371,6 +371,13 @@ int ghip_build_segments(ghip_ctx *ctx, TreeDev &t, bool walk_records)
   HIPCHK(hipGetLastError());
   if(!walk_records)
     return GHIP_OK;
+  return ghip_fill_walk_records(ctx, t);
+}
+
+// the walk's 64-byte records from the element arrays (again after the arrays changed: the drifted tree)
+int ghip_fill_walk_records(ghip_ctx *ctx, TreeDev &t)
+{
+  const TreeSizes *ts = P<TreeSizes>(t.dsz);
   const long long ce = (long long) t.n + t.cap_nodes;   // elements the buffers hold
   if(ce + 2 >= (1LL << 26))
     return ghip_fail(ctx, GHIP_EINVAL, "the walk addresses its 64-byte element records by a 32-bit byte "
@@ -635,7 +642,9 @@ static int prepare_job(ghip_ctx *ctx, const ghip_grav_params *p, int walk, int n
   hipStream_t ps = plan_on ? plan_on : ctx->stream;
   J.walk = walk;
   GCHK(prepare_tables(ctx, p, walk, J.k));
-  walk_layout(ctx->gt, nt, J.sg, &J.nbuckets, walk == GHIP_WALK_EWALD);
+  // (a sub-step on the kept tree of the last full build walks THAT element list; the targets, their
+  // order and the result mapping stay those of the tree of the current positions)
+  walk_layout(ctx->dyn_use ? ctx->dyn : ctx->gt, nt, J.sg, &J.nbuckets, walk == GHIP_WALK_EWALD);
   GCHK(build_plan(ctx, walk == GHIP_WALK_EWALD ? 1 : 0, J.nbuckets, J.sg.ns, J.plan, slot, ps));
   GCHK(ensure_partials(ctx, J.plan.nwaves, slot, J.pb));
   J.counter = ghip_cslot(ctx, walk == GHIP_WALK_EWALD ? GHIP_CK_EWALD : GHIP_CK_NEWTON);
@@ -648,7 +657,7 @@ static int run_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt, hip
   int evi = (J.walk == GHIP_WALK_EWALD) ? 4 : 2;
   ctx->plan_writer[J.walk == GHIP_WALK_EWALD ? 1 : 0] = st;
   HIPCHK(hipEventRecord(ctx->evp[evi], st));
-  launch_walk_any(ctx, J.walk, ctx->gt, J.sg, J.nbuckets, nt, tgt, P<double>(ctx->sx),
+  launch_walk_any(ctx, J.walk, ctx->dyn_use ? ctx->dyn : ctx->gt, J.sg, J.nbuckets, nt, tgt, P<double>(ctx->sx),
                   P<double>(ctx->sy), P<double>(ctx->sz), P<double>(ctx->ssoft),
                   P<double>(ctx->soldacc), J.k, J.counter, J.plan, J.pb, st);
   HIPCHK(hipGetLastError());
@@ -875,13 +884,13 @@ extern "C" int ghip_gravity_ext_soft(ghip_ctx *ctx, const ghip_grav_params *p, i
   HIPCHK(hipMemcpyAsync(dtype, type, (size_t) nt * 4, hipMemcpyHostToDevice, st));
   WalkSeg sg;
   int nbuckets;
-  walk_layout(ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
+  walk_layout(ctx->dyn_use ? ctx->dyn : ctx->gt, nt, sg, &nbuckets, walk == GHIP_WALK_EWALD);
   WalkPlan plan;
   GCHK(build_plan(ctx, 2, nbuckets, sg.ns, plan));
   PartialBufs pb;
   GCHK(ensure_partials(ctx, plan.nwaves, 0, pb));
   unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_EXT);
-  launch_walk_any(ctx, walk, ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
+  launch_walk_any(ctx, walk, ctx->dyn_use ? ctx->dyn : ctx->gt, sg, nbuckets, nt, nullptr, dx, dy, dz, dsoft, dold, k,
                   counter, plan, pb, st);
   k_combine_grav<<<cdiv(nt, 256), 256, 0, st>>>(nt, plan, nullptr, nullptr, P<double>(ctx->tax),
                                                P<double>(ctx->tay), P<double>(ctx->taz),

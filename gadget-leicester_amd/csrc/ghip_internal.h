@@ -347,6 +347,15 @@ struct ghip_ctx
   std::vector<GravCall> grav_log;  // gravity calls since the last tree build
   std::vector<void *> host_pins;   // ranges page-locked by ghip_pin_host
   bool hydro_early = false;        // ghip_set_hydro_release
+  // ---- the gravity tree between two full builds (ghip_set_dynamic_tree, ghip_export.hip): a copy of
+  // the last full build's element list whose nodes are drifted and kicked as forcetree.c:1356-1520
+  // does; the gravity walks of a sub-step read it instead of the tree of the current positions ----
+  bool dyn_on = false, dyn_valid = false, dyn_use = false;
+  TreeDev dyn;
+  DevBuf dyn_ev, dyn_dp;           // double4[nelem]: (vs, vmax) / (dp, kicked) per element
+  DevBuf dyn_eh, dyn_cnt, dyn_fa;  // scratch of the moment pass (export's kernels)
+  DevBuf dyn_kick;                 // double4[nelem]: a kick pass's per-element sums
+  DevBuf kick_dv, kick_flag;       // f64[3][n], i32[n]: velocity changes of the last ghip_advance_timesteps
   // balance of a Newton + Ewald pair (ghip_gravity.hip, pair_balance): dynamic LDS per Newtonian
   // workgroup in use, and a ring of the last pairs' start / end events with the cap they ran under
   int pair_lds = 10240;
@@ -424,6 +433,10 @@ static inline unsigned long long *ghip_rslot(ghip_ctx *ctx, int kind)
 }
 // host copy of a slot buffer added up: out[kind][which], which = 0, 1
 int ghip_read_slots(ghip_ctx *ctx, DevBuf &buf, unsigned long long out[GHIP_CK_COUNT][2]);
+int ghip_dyn_capture(ghip_ctx *ctx);                 // after a full build: copy the gravity tree, vs / vmax per node
+int ghip_dyn_kick_recorded(ghip_ctx *ctx);           // force_kick_node for what ghip_advance_timesteps recorded
+void ghip_dyn_release(ghip_ctx *ctx);
+int ghip_fill_walk_records(ghip_ctx *ctx, TreeDev &t);
 int ghip_gravity_finish_on(ghip_ctx *ctx, double G, int pmgrid, double comoving_fac, int all_shards,
                            hipStream_t st);
 int ghip_join_pair(ghip_ctx *ctx);   // wait for a pair in flight only (entry of the gravity walks)

@@ -52,7 +52,8 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
                                     const double *__restrict__ hsml,
                                     const double *__restrict__ maxsignalvel,
                                     int *__restrict__ timebin, int *__restrict__ ti_begstep,
-                                    int *__restrict__ err, int *errw)
+                                    int *__restrict__ err, int *errw, double *__restrict__ kick_dv,
+                                    int *__restrict__ kick_flag)
 {
 // (errw: asynchronous mode, the pinned word the next synchronising call checks)
 #define D_RAISE(code)                   \
@@ -208,6 +209,13 @@ __global__ void k_advance_timesteps(int nact, const int *__restrict__ act, int n
       entropy[i] = A;
       dtentropy[i] = dA;
     }
+  // a kept tree (ghip_set_dynamic_tree): what force_kick_node(i, dv) receives, timestep.c:584-588
+  if(kick_dv)
+    {
+      for(int j = 0; j < 3; j++)
+        kick_dv[(size_t) j * n + i] = g[j] * dt_gravkick + (gas ? hy[j] * dt_hydrokick : 0.0);
+      kick_flag[i] = 1;
+    }
   for(int j = 0; j < 3; j++)
     vel[(size_t) j * n + i] = v[j];
 }
@@ -337,6 +345,15 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   const int nact = ctx->nactive < 0 ? n : ctx->nactive;
   const int *act = ctx->nactive < 0 ? nullptr : P<int>(ctx->act_host_idx);
   HIPCHK(hipEventRecord(ctx->evp[12], st));
+  // with a kept tree the kicks are recorded and handed to the nodes (force_kick_node inside
+  // do_the_kick, force_finish_kick_nodes at the end of advance_and_find_timesteps, timestep.c:256-263)
+  const bool record = ctx->dyn_on && ctx->dyn_valid && ctx->dyn.n == n;
+  if(record)
+    {
+      GCHK(ghip_ensure(ctx, ctx->kick_dv, 3 * (size_t) n * 8));
+      GCHK(ghip_ensure(ctx, ctx->kick_flag, (size_t) n * 4));
+      HIPCHK(hipMemsetAsync(ctx->kick_flag.p, 0, (size_t) n * 4, st));
+    }
   if(nact > 0)
     k_advance_timesteps<<<cdiv(nact, 256), 256, 0, st>>>(
       nact, act, n, ng, k, P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->f[GHIP_F_VEL]),
@@ -346,7 +363,10 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
       P<double>(ctx->f[GHIP_F_DTENTROPY]), P<double>(ctx->f[GHIP_F_DENSITY]),
       P<double>(ctx->f[GHIP_F_HSML]), P<double>(ctx->f[GHIP_F_MAXSIGNALVEL]),
       P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TI_BEGSTEP]), derr,
-      ctx->async ? ghip_errword(ctx, GHIP_ERRW_TIMESTEP) : nullptr);
+      ctx->async ? ghip_errword(ctx, GHIP_ERRW_TIMESTEP) : nullptr,
+      record ? P<double>(ctx->kick_dv) : nullptr, record ? P<int>(ctx->kick_flag) : nullptr);
+  if(record && nact > 0)
+    GCHK(ghip_dyn_kick_recorded(ctx));
   HIPCHK(hipEventRecord(ctx->evp[13], st));
   HIPCHK(hipGetLastError());
   const bool want_counts = TimeBinCount || TimeBinCountSph;

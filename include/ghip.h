@@ -504,6 +504,39 @@ typedef struct
 /* ---- the path ---- */
 int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double DomainCenter[3],
                     double DomainLen, const double ForceSoftening[6]);
+/* ---- sub-steps on the tree of the last full build (the reference's dynamic tree update,
+ * forcetree.c:1356-1651: force_drift_node, force_kick_node, force_finish_kick_nodes) ----
+ * Without this, every ghip_tree_build builds the tree of the CURRENT positions -- a valid Barnes-Hut
+ * tree, but not the one the reference walks on a sub-step (TreeReconstructFlag == 0): there the cells
+ * are those of the last full build, a node's centre of mass has moved with its mass-weighted velocity
+ * vs, its side length has grown by 2 vmax dt and the momentum of the kicked particles is folded into
+ * vs.  With ghip_set_dynamic_tree(ctx, 1):
+ *   ghip_tree_build        = a full build (force_treebuild); a copy of the gravity tree is kept with
+ *                            vs and vmax per node
+ *   ghip_advance_timesteps   records the velocity change of every particle it kicks and hands Mass dv
+ *                            and max|Vel| to all ancestors (force_kick_node); a host that kicks itself
+ *                            calls ghip_tree_kick_nodes(ctx, n, idx, dv[n][3]) after it has stored the
+ *                            new velocities (ghip_set_field VEL)
+ *   ghip_tree_substep(ctx, dt_drift)
+ *                          = what gravity_tree() does with TreeReconstructFlag == 0: every node of the
+ *                            kept tree goes from the previous sync point to this one (pending kicks
+ *                            into vs, s += vs dt_drift, len += 2 vmax dt_drift; dt_drift = (Ti_Current
+ *                            - Ti_previous) * Timebase_interval, or get_drift_factor in comoving runs)
+ *                            and its particle elements take the resident POS / MASS (drift the
+ *                            particles first: ghip_drift, without box wrapping -- the reference wraps
+ *                            at domain decompositions only); the tree of the current positions is
+ *                            rebuilt as well, for the target order and the gas tree (SPH neighbour sets
+ *                            are geometric: they do not depend on the tree that finds them).
+ *                            The gravity walks read the kept tree until the next ghip_tree_build.
+ * All nodes move at once; the reference moves a node when a walk or a kick first meets it, which is
+ * the same state up to the rounding of s += vs dt in one piece or several.  Not on a multi-GPU shard
+ * and not with ADAPTIVE_GRAVSOFT_FORGAS. */
+int ghip_set_dynamic_tree(ghip_ctx *ctx, int on);
+int ghip_tree_substep(ghip_ctx *ctx, double dt_drift);
+int ghip_tree_kick_nodes(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3);
+/* the kept tree in pre-order (tests): xm = (s or pos, mass), cl = (centre, len), ev = (vs, vmax),
+ * lk = links; NULL = skip */
+int ghip_tree_dump_dynamic(ghip_ctx *ctx, int *nelem, double *xm4, double *cl4, double *ev4, int *lk4);
 /* ADAPTIVE_GRAVSOFT_FORGAS (the shipped Makefile bundle): on != 0 makes the gravitational softening
  * of a gas particle its Hsml instead of ForceSoftening[0], as a target (forcetree.c:1851-1856), as
  * a source (:2038-2058) and in the nodes' maxsoft (:705-726, 845-846), which then opens a node

@@ -119,6 +119,8 @@ typedef struct
   int softset;        /* maxsofttype != 7 */
   /* extNODE */
   double hmax, vmax, divVmax, vs[3];
+  double dp[3];       /* Extnodes[].dp: momentum kicks not yet folded into vs (forcetree.c:1483-1490) */
+  int kicked;         /* BITFLAG_NODEHASBEENKICKED */
 } onode;
 
 struct orc_tree
@@ -327,6 +329,8 @@ static void update_node_recursive(orc_tree *t, int no, int sib, int father)
       nd->hmax = hmax;
       nd->vmax = vmax;
       nd->divVmax = divVmax;
+      nd->dp[0] = nd->dp[1] = nd->dp[2] = 0;
+      nd->kicked = 0;
       nd->multi = (count_particles > 1);
       nd->maxsoft = maxsoft;
       nd->softset = softset;
@@ -572,6 +576,92 @@ void orc_update_hmax(orc_tree *t, int nactive, const int *active, const double *
             break;
           no = nd->father;
         }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the tree between two builds (sub-steps): forcetree.c:1356-1520
+ *
+ * The reference drifts a node when a walk or a kick first meets it at the current time
+ * (force_drift_node, called from forcetree.c:1759, 2007, 2568, 3372, 3914, ngb.c:134, 272, 607 and
+ * from force_kick_node).  A node's state at time T does not depend on WHEN it was brought there --
+ * only on the kicks recorded up to T -- except for the rounding of s += vs * dt in one piece or in
+ * several, so the restatement updates all nodes at once:
+ *   at a sync point:  orc_tree_drift_nodes(dt)   every node from the previous sync point to this one
+ *                     (walks)
+ *                     orc_tree_kick_nodes(...)   the particles kicked at this sync point
+ * ---------------------------------------------------------------------------------------- */
+
+/* force_drift_node (forcetree.c:1356-1452) for every node: a node kicked at the previous sync point
+ * first folds the recorded momentum into vs (:1368-1400), then s += vs * dt_drift, the side length
+ * grows by 2 vmax dt_drift (:1437-1438) and hmax by exp(divVmax dt_drift_hmax / 3) (:1449).
+ * dt_drift = dt_drift_hmax = (time1 - time0) * Timebase_interval, or get_drift_factor(time0, time1)
+ * in comoving runs (:1403-1425; FLTROUNDOFFREDUCTION off). */
+void orc_tree_drift_nodes(orc_tree *t, double dt_drift, double dt_drift_hmax)
+{
+  for(int k = 0; k < t->numnodes; k++)
+    {
+      onode *nd = &t->nodes[k];
+      if(nd->kicked)
+        {
+          double fac = nd->mass ? 1 / nd->mass : 0;
+          for(int j = 0; j < 3; j++)
+            {
+              nd->vs[j] += fac * nd->dp[j];
+              nd->dp[j] = 0;
+            }
+          nd->kicked = 0;
+        }
+      for(int j = 0; j < 3; j++)
+        nd->s[j] += nd->vs[j] * dt_drift;
+      nd->len += 2 * nd->vmax * dt_drift;
+      nd->hmax *= exp(0.333333333333 * nd->divVmax * dt_drift_hmax);
+    }
+}
+
+/* force_kick_node (forcetree.c:1455-1520) for the particles idx[0, n) whose velocities just changed by
+ * dv (the tree's vel[] already holds the NEW velocities, as P[i].Vel does at timestep.c:588): every
+ * ancestor records dp += Mass * dv, vmax = max(vmax, max_j |Vel[j]|) and the KICKED flag. */
+void orc_tree_kick_nodes(orc_tree *t, int n, const int *idx, const double *dv3)
+{
+  for(int k = 0; k < n; k++)
+    {
+      int i = idx[k];
+      double dp[3], vmax = 0;
+      for(int j = 0; j < 3; j++)
+        {
+          dp[j] = t->mass[i] * dv3[3 * (size_t) k + j];
+          double v = fabs(t->vel[3 * (size_t) i + j]);
+          if(v > vmax)
+            vmax = v;
+        }
+      int no = t->father[i];
+      while(no >= 0)
+        {
+          onode *nd = &NODE(t, no);
+          for(int j = 0; j < 3; j++)
+            nd->dp[j] += dp[j];
+          if(nd->vmax < vmax)
+            nd->vmax = vmax;
+          nd->kicked = 1;
+          no = nd->father;
+        }
+    }
+}
+
+/* s, len, vs, vmax of every node (dump order of orc_tree_dump_nodes) */
+void orc_tree_dump_dynamic(const orc_tree *t, double *s3, double *len, double *vs3, double *vmax)
+{
+  for(int k = 0; k < t->numnodes; k++)
+    {
+      const onode *nd = &t->nodes[k];
+      for(int j = 0; j < 3; j++)
+        {
+          s3[3 * k + j] = nd->s[j];
+          vs3[3 * k + j] = nd->vs[j];
+        }
+      len[k] = nd->len;
+      vmax[k] = nd->vmax;
     }
 }
 

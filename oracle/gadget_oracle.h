@@ -62,6 +62,11 @@ void orc_tree_dump_particles(const orc_tree *t, int *nextnode, int *father);
 /* force_update_hmax (forcetree.c:1661-1786): raise hmax/divVmax up the Father chain */
 void orc_update_hmax(orc_tree *t, int nactive, const int *active, const double *hsml,
                      const double *divvel);
+/* the tree between two builds (forcetree.c:1356-1520): force_drift_node for every node,
+ * force_kick_node for the kicked particles */
+void orc_tree_drift_nodes(orc_tree *t, double dt_drift, double dt_drift_hmax);
+void orc_tree_kick_nodes(orc_tree *t, int n, const int *idx, const double *dv3);
+void orc_tree_dump_dynamic(const orc_tree *t, double *s3, double *len, double *vs3, double *vmax);
 
 typedef struct
 {

@@ -62,6 +62,9 @@ def lib():
         L.orc_tree_dump_ext.argtypes = [C.c_void_p] * 6
         L.orc_tree_dump_particles.argtypes = [C.c_void_p] * 3
         L.orc_update_hmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_tree_drift_nodes.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_tree_kick_nodes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_tree_dump_dynamic.argtypes = [C.c_void_p] * 5
         L.orc_gravity.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.orc_gravity_shortrange.argtypes = L.orc_gravity.argtypes
         L.orc_gravity_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
@@ -207,6 +210,26 @@ class Tree:
         self._hs = _f64(hsml)
         self._dv = None if divvel is None else _f64(divvel)
         lib().orc_update_hmax(self.h, len(active), _p(active), _p(self._hs), _p(self._dv))
+
+    # ---- the tree between two builds (forcetree.c:1356-1520) ----
+    def drift_nodes(self, dt_drift, dt_drift_hmax=None):
+        """force_drift_node for every node.  The particles move with the caller: self.pos / self.vel
+        are the arrays the C tree reads (update them in place)."""
+        lib().orc_tree_drift_nodes(self.h, float(dt_drift),
+                                   float(dt_drift if dt_drift_hmax is None else dt_drift_hmax))
+
+    def kick_nodes(self, idx, dv):
+        """force_kick_node for the particles idx, whose self.vel already holds the new velocities."""
+        idx = _i32(idx)
+        dv = _f64(dv)
+        assert dv.shape == (len(idx), 3)
+        lib().orc_tree_kick_nodes(self.h, len(idx), _p(idx), _p(dv))
+
+    def dump_dynamic(self, numnodes):
+        out = {"s": np.zeros((numnodes, 3)), "len": np.zeros(numnodes), "vs": np.zeros((numnodes, 3)),
+               "vmax": np.zeros(numnodes)}
+        lib().orc_tree_dump_dynamic(self.h, _p(out["s"]), _p(out["len"]), _p(out["vs"]), _p(out["vmax"]))
+        return out
 
     # ---- gravity ----
     def gravity(self, params, targets, oldacc, kind="newton", ewald_tab=None):

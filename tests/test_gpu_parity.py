@@ -1835,3 +1835,104 @@ def test_pm_periodic_long_range_force_parity(ng, pmgrid):
                                  boxsize=pr.box, ewald_tab=O.ewald_table(pr.box))
         err = np.linalg.norm(total[sample] - d, axis=1) / np.linalg.norm(d, axis=1)
         assert np.median(err) < 0.01 and np.percentile(err, 95) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodic", [0, 1])
+def test_substeps_walk_the_drifted_and_kicked_tree_of_the_last_full_build(periodic):
+    """Sub-step reuse of the tree (forcetree.c:1356-1651, force_drift_node / force_kick_node): after a
+    full build, three sync points with kicks of random subsets and drifts of everybody.  The gravity
+    walks of a sub-step must make the opening decisions of the reference's DRIFTED tree -- the cells of
+    the full build, centres of mass moved with vs, sides grown by 2 vmax dt -- not those of a tree of
+    the current positions: interaction counts equal the oracle's (orc_tree_drift_nodes /
+    orc_tree_kick_nodes on its insertion tree) and differ from a rebuild's; the kept tree's nodes equal
+    the oracle's node by node; density() on the same sub-step is unchanged by the choice of tree."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=periodic)
+    n, ng = pr.n, pr.ngas
+    rng = np.random.default_rng(17)
+    # room around the particles: they must stay inside the domain cube between full builds
+    c, ce, ln = pr.extent
+    pr.extent = (c - 0.05 * ln, ce.copy(), 1.1 * ln)
+    ext = (pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+    pos, vel = pr.ic["pos"].copy(), pr.ic["vel"].copy()
+    vel += 0.2 * np.abs(vel).max() * rng.standard_normal(vel.shape)
+    fp = pr.device()
+    fp.set_field(B.F_VEL, vel)
+    fp.set_dynamic_tree(True)
+    fp.tree_build(*ext)
+    T = O.Tree(pos, vel, pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0, extent=pr.extent)
+    tab = O.ewald_table(pr.box) if periodic else None
+    walk = B.WALK_NEWTON_EWALD if periodic else B.WALK_NEWTON
+    everybody = np.arange(n, dtype=np.int32)
+
+    def oracle_gravity(tree, theta, tg, old):
+        a, cst = tree.gravity(pr.o_grav(theta), tg, old)
+        if periodic:
+            tree.gravity_ewald_add(pr.o_grav(theta), tab, tg, old, a, cst)
+        return a, cst
+
+    # step 0 on the fresh tree: Barnes-Hut pass for OldAcc
+    fp.gravity(pr.g_grav(pr.theta), walk)
+    a0, c0 = oracle_gravity(T, pr.theta, everybody, np.zeros(n))
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), c0)
+    old = np.linalg.norm(a0, axis=1)
+    fp.set_field(B.F_OLDACC, old)
+    vscale = np.abs(vel).max()
+    differs = 0
+    for step in range(3):
+        # kicks of this sync point (timestep.c:584-588): new velocities, then force_kick_node
+        act = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+        dv = 0.1 * vscale * rng.standard_normal((len(act), 3))
+        T.vel[act] += dv
+        T.kick_nodes(act, dv)
+        fp.set_field(B.F_VEL, T.vel)
+        fp.tree_kick_nodes(act, dv)
+        # everybody drifts to the next sync point; no full build
+        dt = 0.004 * pr.box / vscale * (1 + step)
+        T.pos += T.vel * dt
+        T.drift_nodes(dt)
+        fp.set_field(B.F_POS, T.pos)
+        fp.tree_substep(dt)
+        # the kept tree, node by node (cells are matched by their centres, which never move)
+        d = fp.tree_dump_dynamic()
+        od = T.dump()
+        oy = T.dump_dynamic(T.numnodes)
+        nodes = d["lk"][:, 1] < 0
+        og = np.lexsort(np.round(d["cl"][nodes][:, :3], 14).T[::-1])
+        oo = np.lexsort(np.round(od["center"], 14).T[::-1])
+        assert np.array_equal(np.round(d["cl"][nodes][og][:, :3], 14), np.round(od["center"][oo], 14))
+        assert np.abs(d["xm"][nodes][og][:, :3] - oy["s"][oo]).max() < 1e-13 * pr.box
+        assert relerr(d["cl"][nodes][og][:, 3], oy["len"][oo]) < 1e-14
+        assert np.abs(d["ev"][nodes][og][:, :3] - oy["vs"][oo]).max() < 1e-13 * vscale
+        assert np.array_equal(d["ev"][nodes][og][:, 3], oy["vmax"][oo])
+        # gravity for the particles active at this sync point
+        tg = np.sort(rng.choice(n, n // 4, replace=False)).astype(np.int32)
+        fp.set_active(tg)
+        fp.gravity(pr.g_grav(0.0), walk)
+        acc, cost = fp.get_field(B.F_GRAVACCEL)[tg], fp.get_field(B.F_GRAVCOST)[tg]
+        oa, oc = oracle_gravity(T, 0.0, tg, old)
+        assert np.array_equal(cost, oc), "interaction counts on the drifted tree (sub-step %d)" % step
+        assert relerr(acc, oa) < TOL
+        # ... which are not those of a tree of the current positions
+        Tn = O.Tree(T.pos, T.vel, pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0,
+                    extent=pr.extent)
+        _, cn = oracle_gravity(Tn, 0.0, tg, old)
+        differs += int((cn != oc).sum())
+        # SPH on the same sub-step: neighbour sets are geometric, the tree of the current positions serves
+        if step == 2:
+            act_g = tg[tg < ng]
+            fp.set_active(act_g)
+            fp.density(pr.g_dens())
+            odn = Tn.density(pr.o_dens(), act_g, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                             pr.ti_begstep, pr.hsml0)
+            assert relerr(fp.get_field(B.F_DENSITY)[act_g], odn["density"][act_g]) < TOL
+        fp.set_active(None)
+    assert differs > 0
+    # a full build ends the sub-stepping: the walks read the tree of the current positions again
+    fp.tree_build(*ext)
+    fp.gravity(pr.g_grav(0.0), walk)
+    Tn = O.Tree(T.pos, T.vel, pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0, extent=pr.extent)
+    _, cn = oracle_gravity(Tn, 0.0, everybody, old)
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), cn)
+    fp.close()

@@ -536,3 +536,50 @@ def test_cooling_and_starformation_update_by_hand():
     assert abs(d[0] - 0.65) < 1e-15 and i2[0] == 0 and flag[0] == 0
     assert flag[1] == 1 and d[1] == 0.5 and i2[1] == 1.0          # qualifies as a sink: untouched
     assert d[2] == -0.5 * 2.0 / 2.0 and flag[2] == 0              # floor of sfr_eff.c:590-591
+
+
+def test_drifted_and_kicked_tree_keeps_exact_moments_and_covering_cells():
+    """The tree between two builds (forcetree.c:1356-1520, restated in orc_tree_drift_nodes /
+    orc_tree_kick_nodes), pinned by what it must conserve rather than by its own arithmetic: after
+    kicks of random subsets and drifts, every node's s is still the centre of mass of ITS particles at
+    their current positions, its vs their mass-weighted velocity (once the pending kicks are folded in
+    by the next drift), and its grown cell (side len += 2 vmax dt) still contains them."""
+    rng = np.random.default_rng(7)
+    n = 1500
+    pos = rng.random((n, 3))
+    vel = 0.3 * rng.standard_normal((n, 3))
+    mass = 0.5 + rng.random(n)
+    T = O.Tree(pos, vel, mass, np.ones(n, np.int32), np.full(6, 0.01))
+    d0 = T.dump()
+    # membership: particle -> all ancestors, from the insertion tree's father links
+    nn = T.numnodes
+    father_n = d0["father"]                    # per node (node numbering: n + k), -1 at the root
+    members = [[] for _ in range(nn)]
+    for i in range(n):
+        no = d0["p_father"][i]
+        while no >= 0:
+            members[no - n].append(i)
+            no = father_n[no - n]
+    t_since = 0.0
+    for step in range(4):
+        act = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+        dv = 0.05 * rng.standard_normal((len(act), 3))
+        T.vel[act] += dv                        # P[i].Vel += dv, then force_kick_node (timestep.c:584-588)
+        T.kick_nodes(act, dv)
+        dt = 0.01 * (1 + step)
+        T.pos += T.vel * dt                     # drift_particle of every particle
+        T.drift_nodes(dt)
+        t_since += dt
+        dd = T.dump_dynamic(nn)
+        for k in range(0, nn, 7):
+            m = np.asarray(members[k])
+            if len(m) == 0:
+                continue
+            w = T.mass[m]
+            com = (w[:, None] * T.pos[m]).sum(axis=0) / w.sum()
+            assert np.abs(dd["s"][k] - com).max() < 1e-12, (step, k)
+            vcm = (w[:, None] * T.vel[m]).sum(axis=0) / w.sum()
+            assert np.abs(dd["vs"][k] - vcm).max() < 1e-12
+            half = 0.5 * dd["len"][k]
+            assert np.all(np.abs(T.pos[m] - d0["center"][k]) <= half * (1 + 1e-12)), (step, k)
+            assert dd["vmax"][k] >= np.abs(T.vel[m]).max() - 1e-15 or step == 0
