@@ -184,7 +184,8 @@ EXPORTS = [
     "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
     "ghip_gravity_vacuum_energy", "ghip_pm_kick",
     "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
-    "ghip_set_dynamic_tree", "ghip_tree_substep", "ghip_tree_kick_nodes", "ghip_tree_dump_dynamic",
+    "ghip_set_dynamic_tree", "ghip_tree_substep", "ghip_tree_kick_nodes", "ghip_tree_kick_nodes_vmax",
+    "ghip_tree_dump_dynamic",
     "ghip_gas_block_mixed", "ghip_set_hydro_release", "ghip_download_aos_async",
     "ghip_gravity_to_records", "ghip_pin_host", "ghip_unpin_host", "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",

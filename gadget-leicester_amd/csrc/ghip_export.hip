@@ -352,7 +352,8 @@ void ghip_dyn_release(ghip_ctx *ctx)
 __global__ void k_dyn_kick_particles(int nelem, int n, const int4 *__restrict__ lk,
                                      const int *__restrict__ perm, const double *__restrict__ mass,
                                      const double *__restrict__ vel, const double *__restrict__ dv,
-                                     const int *__restrict__ flag, double4 *__restrict__ up)
+                                     const double *__restrict__ vmaxk, const int *__restrict__ flag,
+                                     double4 *__restrict__ up)
 {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if(e >= nelem)
@@ -367,7 +368,9 @@ __global__ void k_dyn_kick_particles(int nelem, int n, const int4 *__restrict__ 
       return;
     }
   double m = mass[i];
-  double vmax = fmax(fabs(vel[i]), fmax(fabs(vel[(size_t) n + i]), fabs(vel[2 * (size_t) n + i])));
+  // (vmaxk: the caller's max_j |Vel_j| where the resident VEL is not the kicked one yet)
+  double vmax = vmaxk ? vmaxk[i]
+                      : fmax(fabs(vel[i]), fmax(fabs(vel[(size_t) n + i]), fabs(vel[2 * (size_t) n + i])));
   up[e] = make_double4(m * dv[i], m * dv[(size_t) n + i], m * dv[2 * (size_t) n + i], vmax);
 }
 
@@ -408,14 +411,14 @@ __global__ void k_dyn_kick_level(int nelem, int level, const int4 *__restrict__ 
     }
 }
 
-static int dyn_kick_pass(ghip_ctx *ctx, const double *dv, const int *flag)
+static int dyn_kick_pass(ghip_ctx *ctx, const double *dv, const int *flag, const double *vmaxk = nullptr)
 {
   TreeDev &d = ctx->dyn;
   hipStream_t st = ctx->stream;
   const int nelem = d.nelem;
   k_dyn_kick_particles<<<cdiv(nelem, 256), 256, 0, st>>>(
     nelem, ctx->n, P<int4>(d.lk), P<int>(d.perm), P<double>(ctx->f[GHIP_F_MASS]),
-    P<double>(ctx->f[GHIP_F_VEL]), dv, flag, P<double4>(ctx->dyn_kick));
+    P<double>(ctx->f[GHIP_F_VEL]), dv, vmaxk, flag, P<double4>(ctx->dyn_kick));
   for(int L = d.maxlevel; L >= 0; L--)
     k_dyn_kick_level<<<cdiv(nelem, 256), 256, 0, st>>>(nelem, L, P<int4>(d.lk), P<double4>(ctx->dyn_kick),
                                                        P<double4>(ctx->dyn_dp), P<double4>(ctx->dyn_ev));
@@ -431,8 +434,10 @@ int ghip_dyn_kick_recorded(ghip_ctx *ctx)
   return dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag));
 }
 
+// (a particle kicked twice at one sync point -- gravity, then a feedback kick -- hands up the sum)
 __global__ void k_dyn_scatter_kicks(int nk, int n, const int *__restrict__ idx, const double *__restrict__ dv3,
-                                    double *__restrict__ dv, int *__restrict__ flag)
+                                    const double *__restrict__ vmaxk, double *__restrict__ dv,
+                                    int *__restrict__ flag)
 {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= nk)
@@ -440,12 +445,34 @@ __global__ void k_dyn_scatter_kicks(int nk, int n, const int *__restrict__ idx, 
   int i = idx[k];
   if(i < 0 || i >= n)
     return;
-  flag[i] = 1;
+  const bool first = atomicExch(&flag[i], 1) == 0;
   for(int j = 0; j < 3; j++)
-    dv[(size_t) j * n + i] = dv3[3 * (size_t) k + j];
+    {
+      if(first)
+        dv[(size_t) j * n + i] = dv3[3 * (size_t) k + j];
+      else
+        atomicAdd(&dv[(size_t) j * n + i], dv3[3 * (size_t) k + j]);
+    }
+  if(vmaxk)
+    dv[3 * (size_t) n + i] = vmaxk[k];   // (the later entry of a particle carries its final velocity)
 }
 
+static int kick_nodes_host(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3, const double *vmaxk);
+
 extern "C" int ghip_tree_kick_nodes(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3)
+{
+  return kick_nodes_host(ctx, nkicked, idx, dv3, nullptr);
+}
+
+extern "C" int ghip_tree_kick_nodes_vmax(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3,
+                                         const double *vmaxk)
+{
+  if(!vmaxk && nkicked > 0)
+    return GHIP_EINVAL;
+  return kick_nodes_host(ctx, nkicked, idx, dv3, vmaxk);
+}
+
+static int kick_nodes_host(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3, const double *vmaxk)
 {
   if(!ctx || nkicked < 0 || (nkicked > 0 && (!idx || !dv3)))
     return GHIP_EINVAL;
@@ -457,17 +484,21 @@ extern "C" int ghip_tree_kick_nodes(ghip_ctx *ctx, int nkicked, const int *idx, 
     return GHIP_OK;
   const size_t n = (size_t) ctx->n;
   hipStream_t st = ctx->stream;
-  GCHK(ghip_ensure(ctx, ctx->kick_dv, 3 * n * 8));
+  GCHK(ghip_ensure(ctx, ctx->kick_dv, 4 * n * 8));
   GCHK(ghip_ensure(ctx, ctx->kick_flag, n * 4));
-  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nkicked * 28 + 64));
+  GCHK(ghip_ensure(ctx, ctx->stage, (size_t) nkicked * 36 + 64));
   int *didx = P<int>(ctx->stage);
   double *ddv = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->stage.p) + (((size_t) nkicked * 4 + 15) & ~(size_t) 15));
+  double *dvm = ddv + 3 * (size_t) nkicked;
   HIPCHK(hipMemcpyAsync(didx, idx, (size_t) nkicked * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ddv, dv3, (size_t) nkicked * 24, hipMemcpyHostToDevice, st));
+  if(vmaxk)
+    HIPCHK(hipMemcpyAsync(dvm, vmaxk, (size_t) nkicked * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(ctx->kick_flag.p, 0, n * 4, st));
-  k_dyn_scatter_kicks<<<cdiv(nkicked, 256), 256, 0, st>>>(nkicked, ctx->n, didx, ddv, P<double>(ctx->kick_dv),
-                                                          P<int>(ctx->kick_flag));
-  GCHK(dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag)));
+  k_dyn_scatter_kicks<<<cdiv(nkicked, 256), 256, 0, st>>>(nkicked, ctx->n, didx, ddv, vmaxk ? dvm : nullptr,
+                                                          P<double>(ctx->kick_dv), P<int>(ctx->kick_flag));
+  GCHK(dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag),
+                     vmaxk ? P<double>(ctx->kick_dv) + 3 * n : nullptr));
   HIPCHK(ghip_stream_sync(ctx, st));   // (idx / dv3 are the caller's)
   return GHIP_OK;
 }

@@ -350,7 +350,7 @@ extern "C" int ghip_advance_timesteps(ghip_ctx *ctx, const ghip_kick_params *p,
   const bool record = ctx->dyn_on && ctx->dyn_valid && ctx->dyn.n == n;
   if(record)
     {
-      GCHK(ghip_ensure(ctx, ctx->kick_dv, 3 * (size_t) n * 8));
+      GCHK(ghip_ensure(ctx, ctx->kick_dv, 4 * (size_t) n * 8));
       GCHK(ghip_ensure(ctx, ctx->kick_flag, (size_t) n * 4));
       HIPCHK(hipMemsetAsync(ctx->kick_flag.p, 0, (size_t) n * 4, st));
     }

@@ -109,6 +109,11 @@ static int Phase = 0;            /* 1 after gravity_tree(), 2 after density(): a
 static int GravPending = 0;      /* overlap_sph: walks in flight, post-pass + download still to do */
 static int GasPending = 0;       /* overlap_sph: P[] is on the device, SphP[] still to follow */
 static int GravPendingActive = 0;
+/* cfg.dynamic_tree: the tree force_treebuild() left on the device is kept across sub-steps */
+static int KeptTree = 0, KeptN = -1, KeptTi = 0;
+static int *KickIdx = NULL;
+static double *KickDv = NULL, *KickVmax = NULL;
+static int KickN = 0, KickCap = 0;
 /* cfg.pin_records: the record arrays page-locked so far */
 static void *PinP, *PinS;
 static size_t PinPBytes, PinSBytes;
@@ -215,6 +220,13 @@ int gadget_force_init(const struct gadget_force_config *cfg)
   RcclConnected = 0;
   if(!RecP)
     lay_defaults();
+  KeptTree = 0;
+  KickN = 0;
+  if(cfg->dynamic_tree && ghip_set_dynamic_tree(Ctx, 1) != GHIP_OK)
+    {
+      snprintf(ErrBuf, sizeof(ErrBuf), "ghip_set_dynamic_tree: %s", ghip_last_error(Ctx));
+      return GHIP_EINVAL;
+    }
   /* (measured, not kept as the default: releasing the hydro kernel at once so that the SphP[] block
    * crosses the link under the walks -- the kernel does not get its registers before the Ewald walk
    * drains anyway; GADGET_FORCE_HYDRO_EARLY=1 reproduces it) */
@@ -257,6 +269,12 @@ void gadget_force_finalize(void)
     }
   PinP = PinS = NULL;
   PinPBytes = PinSBytes = 0;
+  free(KickIdx);
+  free(KickDv);
+  KickIdx = NULL;
+  KickDv = KickVmax = NULL;
+  KickN = KickCap = 0;
+  KeptTree = 0;
   Ctx = NULL;
   free(ActiveBuf);
   ActiveBuf = NULL;
@@ -768,6 +786,10 @@ int force_treebuild(int npart, void *mp)
     return -1;
   ghip_sync(Ctx);
   TreeOnDevice = 1;
+  KeptTree = Cfg.dynamic_tree;   /* (ghip_tree_build kept a copy with vs / vmax per node) */
+  KeptN = NumPart;
+  KeptTi = All.Ti_Current;
+  KickN = 0;
   ghip_stats st;
   ghip_get_stats(Ctx, &st);
   (void) npart;
@@ -795,11 +817,73 @@ static int ensure_tree_split(int split)
     }
   if(TreeReconstructFlag || !TreeOnDevice)
     {
+      /* gravtree.c:60-70.  cfg.dynamic_tree and no reconstruction asked for: the tree of the last
+       * force_treebuild() goes to the current time (force_drift_node for every node, the kicks
+       * recorded since folded in) and the walks read it */
+      if(Cfg.dynamic_tree && !TreeReconstructFlag && KeptTree && KeptN == NumPart && !All.ComovingIntegrationOn &&
+         NTask == 1)
+        {
+          const double dt_drift = (All.Ti_Current - KeptTi) * All.Timebase_interval;   /* forcetree.c:1414 */
+          if(chk(ghip_tree_substep(Ctx, dt_drift), "ghip_tree_substep"))
+            return -1;
+          KeptTi = All.Ti_Current;
+          TreeOnDevice = 1;
+          return 0;
+        }
       if(force_treebuild(NumPart, NULL) < 0)
         return -1;
       TreeReconstructFlag = 0;
     }
   return 0;
+}
+
+/* forcetree.c:1455-1520: collected here, applied by force_finish_kick_nodes() */
+void force_kick_node(int i, MyFloat *dv)
+{
+  if(!Cfg.dynamic_tree || !KeptTree || i < 0 || i >= NumPart)
+    return;
+  if(KickN >= KickCap)
+    {
+      int nc = KickCap ? 2 * KickCap : 4096;
+      int *ni = (int *) realloc(KickIdx, (size_t) nc * sizeof(int));
+      if(ni)
+        KickIdx = ni;
+      double *nd = (double *) realloc(KickDv, (size_t) nc * 4 * sizeof(double));
+      if(!ni || !nd)
+        {
+          endrun(90003);
+          return;
+        }
+      /* (layout [cap][3] dv, then [cap] vmax: re-pack the old entries behind the grown dv block) */
+      if(KickN > 0)
+        memmove(nd + 3 * (size_t) nc, nd + 3 * (size_t) KickCap, (size_t) KickN * sizeof(double));
+      KickDv = nd;
+      KickVmax = nd + 3 * (size_t) nc;
+      KickCap = nc;
+    }
+  KickIdx[KickN] = i;
+  double vmax = 0;
+  for(int j = 0; j < 3; j++)
+    {
+      KickDv[3 * (size_t) KickN + j] = dv[j];
+      double v = fabs(PF64(i, Lay.p_vel)[j]);   /* :1478-1480: P[i].Vel already holds the new velocity */
+      if(v > vmax)
+        vmax = v;
+    }
+  KickVmax[KickN] = vmax;
+  KickN++;
+}
+
+/* forcetree.c:1522-1651 (single rank: nothing to exchange) */
+void force_finish_kick_nodes(void)
+{
+  if(!Cfg.dynamic_tree || !KeptTree || KickN == 0 || !Ctx)
+    {
+      KickN = 0;
+      return;
+    }
+  chk(ghip_tree_kick_nodes_vmax(Ctx, KickN, KickIdx, KickDv, KickVmax), "ghip_tree_kick_nodes_vmax");
+  KickN = 0;
 }
 
 static int ensure_tree(void)

@@ -71,7 +71,7 @@ class Config(C.Structure):
     _fields_ = [("periodic", C.c_int), ("pmgrid", C.c_int), ("unequal_softenings", C.c_int),
                 ("device", C.c_int), ("black_holes", C.c_int), ("dust", C.c_int),
                 ("accretion_of_dust_only", C.c_int), ("accretion_density", C.c_int),
-                ("overlap_sph", C.c_int), ("pin_records", C.c_int)]
+                ("overlap_sph", C.c_int), ("dynamic_tree", C.c_int), ("pin_records", C.c_int)]
 
 
 class BhLayout(C.Structure):
@@ -120,7 +120,7 @@ EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
            "gadget_force_ctx", "gadget_force_layout", "gadget_force_set_endrun",
            "gadget_force_mark_dirty", "endrun", "set_softenings", "data_index_compare",
            "mysort_dataindex", "domain_findExtent",
-           "force_treebuild", "ewald_init", "gravity_tree", "density", "density_isactive",
+           "force_treebuild", "force_kick_node", "force_finish_kick_nodes", "ewald_init", "gravity_tree", "density", "density_isactive",
            "force_update_hmax", "hydro_force", "force_treeevaluate",
            "force_treeevaluate_shortrange", "force_treeevaluate_ewald_correction",
            "density_evaluate", "hydro_evaluate", "ngb_treefind_variable", "ngb_treefind_pairs",
@@ -194,7 +194,7 @@ class Host:
 
     def __init__(self, periodic=1, pmgrid=0, unequal=0, device=0, black_holes=0, dust=0,
                  overlap_sph=0, accretion_of_dust_only=0, accretion_density=0, rank=0, nranks=1,
-                 pin_records=0):
+                 pin_records=0, dynamic_tree=0):
         self.L = lib()
         self.endrun_codes = []
         self._cb = ENDRUN_CB(lambda code: self.endrun_codes.append(code))
@@ -202,7 +202,7 @@ class Host:
         self._seti("ThisTask", rank)
         self._seti("NTask", nranks)
         cfg = Config(periodic, pmgrid, unequal, device, black_holes, dust, accretion_of_dust_only,
-                     accretion_density, overlap_sph, pin_records)
+                     accretion_density, overlap_sph, dynamic_tree, pin_records)
         rc = self.L.gadget_force_init(C.byref(cfg))
         if rc != 0:
             raise RuntimeError("gadget_force_init failed (%d): %s" %
@@ -314,6 +314,15 @@ class Host:
         return (np.array(d3.in_dll(self.L, "DomainCorner")),
                 np.array(d3.in_dll(self.L, "DomainCenter")),
                 C.c_double.in_dll(self.L, "DomainLen").value)
+
+    def set_domain(self, corner, center, length):
+        """DomainCorner / DomainCenter / DomainLen as a domain decomposition left them."""
+        d3 = C.c_double * 3
+        for name, v in (("DomainCorner", corner), ("DomainCenter", center)):
+            a = d3.in_dll(self.L, name)
+            for j in range(3):
+                a[j] = float(v[j])
+        C.c_double.in_dll(self.L, "DomainLen").value = float(length)
 
     def ngblist(self, count):
         ptr = C.POINTER(C.c_int).in_dll(self.L, "Ngblist")

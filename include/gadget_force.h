@@ -280,6 +280,14 @@ struct gadget_force_config
                               for accel.c's sequence (accel.c:61-106: nothing reads P[].g.GravAccel
                               between the four calls); 0 (default): every driver returns with its own
                               results in P[] / SphP[] */
+  int dynamic_tree;        /* All.DoDynamicUpdate: 1 = a gravity_tree() with TreeReconstructFlag == 0 walks
+                              the tree of the last force_treebuild(), its nodes drifted and kicked as
+                              force_drift_node / force_kick_node / force_finish_kick_nodes do
+                              (forcetree.c:1356-1651; ghip_tree_substep), instead of a tree of the
+                              current positions.  force_kick_node() and force_finish_kick_nodes() below
+                              are then the reference's (timestep.c:261, 588); the library's own
+                              advance_and_find_timesteps() hands its kicks to the nodes itself.
+                              Non-comoving runs; 0 (default): every gravity_tree() rebuilds */
   int pin_records;         /* 1: page-lock the first NumPart / N_gas records of P[] / SphP[] when they
                               are first uploaded (again when the arrays move or grow), so the record
                               copies run at the link's rate; released by gadget_force_finalize().  The
@@ -345,6 +353,10 @@ int data_index_compare(const void *a, const void *b);
 void mysort_dataindex(void *b, size_t n, size_t s, int (*cmp)(const void *, const void *));
 void domain_findExtent(void);
 int force_treebuild(int npart, void *mp);
+/* forcetree.c:1455, 1522 (cfg.dynamic_tree): the momentum a kicked particle hands to its ancestors;
+ * collected per call and applied to the kept tree by force_finish_kick_nodes() */
+void force_kick_node(int i, MyFloat *dv);
+void force_finish_kick_nodes(void);
 void ewald_init(void);
 void gravity_tree(void);
 void density(void);

@@ -534,6 +534,11 @@ int ghip_tree_build(ghip_ctx *ctx, const double DomainCorner[3], const double Do
 int ghip_set_dynamic_tree(ghip_ctx *ctx, int on);
 int ghip_tree_substep(ghip_ctx *ctx, double dt_drift);
 int ghip_tree_kick_nodes(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3);
+/* the same when the resident VEL is not the kicked one yet: vmax[k] = max_j |P[idx[k]].Vel[j]| of the
+ * new velocity travels with the kick (what force_kick_node computes itself, forcetree.c:1478-1480).
+ * A particle listed twice hands up the sum of its kicks. */
+int ghip_tree_kick_nodes_vmax(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3,
+                              const double *vmax);
 /* the kept tree in pre-order (tests): xm = (s or pos, mass), cl = (centre, len), ev = (vs, vmax),
  * lk = links; NULL = skip */
 int ghip_tree_dump_dynamic(ghip_ctx *ctx, int *nelem, double *xm4, double *cl4, double *ev4, int *lk4);
