@@ -183,7 +183,7 @@ EXPORTS = [
     "ghip_timestep_endrun_code", "ghip_velocity_moments", "ghip_download_aos_kick",
     "ghip_tree_export", "ghip_pm_periodic", "ghip_set_adaptive_gravsoft", "ghip_gravity_ext_soft",
     "ghip_gravity_vacuum_energy", "ghip_pm_kick",
-    "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_keys", "ghip_dd_find_split",
+    "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_set_segments", "ghip_dd_keys", "ghip_dd_find_split",
     "ghip_set_dynamic_tree", "ghip_tree_substep", "ghip_tree_kick_nodes", "ghip_tree_kick_nodes_vmax",
     "ghip_tree_dump_dynamic",
     "ghip_gas_block_mixed", "ghip_set_hydro_release", "ghip_download_aos_async",
@@ -260,6 +260,7 @@ def lib():
         L.ghip_dd_init.argtypes = [vp, C.c_int, C.c_int]
         L.ghip_dd_set_domain.argtypes = [vp, vp, vp, C.c_double, vp]
         L.ghip_dd_set_splits.argtypes = [vp, vp]
+        L.ghip_dd_set_segments.argtypes = [vp, C.c_int, vp, vp]
         L.ghip_dd_keys.argtypes = [vp, vp]
         L.ghip_dd_find_split.argtypes = [C.c_int, C.c_int, vp, vp, vp]
         L.ghip_dd_set_ghost_margin.argtypes = [vp, C.c_double]
@@ -746,6 +747,12 @@ class ForcePath:
 
     def dd_exchange_host(self, fn):
         self._chk(self.L.ghip_dd_exchange_host(self.h, fn, None))
+
+    def dd_set_segments(self, keys, owner):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        owner = np.ascontiguousarray(owner, np.int32)
+        assert len(keys) == len(owner) + 1
+        self._chk(self.L.ghip_dd_set_segments(self.h, len(owner), _ptr(keys), _ptr(owner)))
 
     def dd_run_host(self, op, params, allgather, walk=0):
         """The operation with every exchange staged through the host and `allgather(send: bytes)

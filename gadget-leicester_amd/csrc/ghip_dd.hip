@@ -54,6 +54,7 @@ extern "C" int ghip_dd_exchange(ghip_ctx *ctx);
 // ---------------------------------------------------------------------------------------------
 // set-up
 // ---------------------------------------------------------------------------------------------
+static int dd_store_segments(ghip_ctx *ctx, int nseg, const unsigned long long *keys, const int *owner);
 extern "C" int ghip_dd_init(ghip_ctx *ctx, int rank, int nranks)
 {
   if(ctx)
@@ -74,7 +75,7 @@ extern "C" int ghip_dd_init(ghip_ctx *ctx, int rank, int nranks)
   ctx->st.built = false;
   ctx->shard_rank = 0;   // (the replicated-source sharding of ghip_set_shard is a different mode)
   ctx->shard_n = 1;
-  return GHIP_OK;
+  return ghip_dd_set_splits(ctx, D.splits);
 }
 
 extern "C" int ghip_dd_set_domain(ghip_ctx *ctx, const double corner[3], const double center[3],
@@ -95,6 +96,47 @@ extern "C" int ghip_dd_set_domain(ghip_ctx *ctx, const double corner[3], const d
   return GHIP_OK;
 }
 
+// ownership of the curve: merge neighbours of one owner, drop empty pieces, keep device copies
+static int dd_store_segments(ghip_ctx *ctx, int nseg, const unsigned long long *keys, const int *owner)
+{
+  DDState &D = ctx->dd;
+  std::vector<unsigned long long> k, lo, hi;
+  std::vector<int> o;
+  for(int s = 0; s < nseg; s++)
+    {
+      if(keys[s + 1] == keys[s])
+        continue;
+      if(!o.empty() && o.back() == owner[s])
+        continue;   // (same owner as the piece before: one piece)
+      k.push_back(keys[s]);
+      o.push_back(owner[s]);
+    }
+  if(k.empty() || k[0] != 0)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd: the key ranges do not start at 0");
+  k.push_back(1ULL << 63);
+  const int m = (int) o.size();
+  for(int s = 0; s < m; s++)
+    if(o[s] == D.rank)
+      {
+        lo.push_back(k[s]);
+        hi.push_back(k[s + 1]);
+      }
+  D.nseg = m;
+  D.nown = (int) lo.size();
+  GCHK(ghip_ensure(ctx, D.segkey, (size_t) (m + 1) * 8));
+  GCHK(ghip_ensure(ctx, D.segowner, (size_t) m * 4));
+  GCHK(ghip_ensure(ctx, D.ownlo, (size_t) (D.nown > 0 ? D.nown : 1) * 8));
+  GCHK(ghip_ensure(ctx, D.ownhi, (size_t) (D.nown > 0 ? D.nown : 1) * 8));
+  HIPCHK(hipMemcpy(D.segkey.p, k.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(D.segowner.p, o.data(), (size_t) m * 4, hipMemcpyHostToDevice));
+  if(D.nown > 0)
+    {
+      HIPCHK(hipMemcpy(D.ownlo.p, lo.data(), (size_t) D.nown * 8, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(D.ownhi.p, hi.data(), (size_t) D.nown * 8, hipMemcpyHostToDevice));
+    }
+  return GHIP_OK;
+}
+
 extern "C" int ghip_dd_set_splits(ghip_ctx *ctx, const unsigned long long *splits)
 {
   if(!ctx || !splits || !ctx->dd.on)
@@ -108,7 +150,28 @@ extern "C" int ghip_dd_set_splits(ghip_ctx *ctx, const unsigned long long *split
     }
   if(D.splits[0] != 0 || D.splits[D.nranks] < (1ULL << 63))
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_set_splits: the ranges must cover [0, 2^63)");
-  return GHIP_OK;
+  std::vector<unsigned long long> keys(D.splits, D.splits + D.nranks + 1);
+  std::vector<int> owner(D.nranks);
+  for(int r = 0; r < D.nranks; r++)
+    owner[r] = r;
+  return dd_store_segments(ctx, D.nranks, keys.data(), owner.data());
+}
+
+extern "C" int ghip_dd_set_segments(ghip_ctx *ctx, int nseg, const unsigned long long *keys, const int *owner)
+{
+  if(!ctx || !keys || !owner || !ctx->dd.on || nseg < 1)
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_set_segments: call ghip_dd_init first; nseg >= 1");
+  DDState &D = ctx->dd;
+  for(int s = 0; s < nseg; s++)
+    {
+      if(keys[s + 1] < keys[s])
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_set_segments: keys must not decrease");
+      if(owner[s] < 0 || owner[s] >= D.nranks)
+        return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_set_segments: owner %d of segment %d is not a rank", owner[s], s);
+    }
+  if(keys[0] != 0 || keys[nseg] < (1ULL << 63))
+    return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_set_segments: the segments must cover [0, 2^63)");
+  return dd_store_segments(ctx, nseg, keys, owner);
 }
 
 extern "C" int ghip_dd_set_ghost_margin(ghip_ctx *ctx, double margin)
@@ -189,9 +252,30 @@ extern "C" int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host)
 
 // every local particle must lie in this shard's key range (the host's domain decomposition, or
 // ghip's own migration, guarantees it): a stray would be counted in nobody's cells
+// does [lo, hi) lie inside ONE of this rank's own pieces of the curve?
+__device__ __forceinline__ bool d_owned_range(unsigned long long lo, unsigned long long hi, int nown,
+                                              const unsigned long long *__restrict__ ownlo,
+                                              const unsigned long long *__restrict__ ownhi)
+{
+  int a = 0, b = nown - 1, j = -1;   // largest j with ownlo[j] <= lo
+  while(a <= b)
+    {
+      int mid = (a + b) >> 1;
+      if(ownlo[mid] <= lo)
+        {
+          j = mid;
+          a = mid + 1;
+        }
+      else
+        b = mid - 1;
+    }
+  return j >= 0 && hi <= ownhi[j];
+}
+
 __global__ void k_dd_check_range(int n, const double *__restrict__ x, const double *__restrict__ y,
                                  const double *__restrict__ z, double cx, double cy, double cz,
-                                 double fac, unsigned long long klo, unsigned long long khi,
+                                 double fac, int nown, const unsigned long long *__restrict__ ownlo,
+                                 const unsigned long long *__restrict__ ownhi,
                                  int *__restrict__ errword)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,7 +284,7 @@ __global__ void k_dd_check_range(int n, const double *__restrict__ x, const doub
   // (a particle outside the domain cube: error 6, the host must give a fresh extent first)
   unsigned long long k = d_peano21(d_cell21(x[i], cx, fac, errword), d_cell21(y[i], cy, fac, errword),
                                    d_cell21(z[i], cz, fac, errword));
-  if(k < klo || k >= khi)
+  if(!d_owned_range(k, k + 1, nown, ownlo, ownhi))
     *(volatile int *) errword = 5;
 }
 
@@ -402,7 +486,8 @@ struct LetK
   double boxsize, boxhalf;
   int periodic, unequal;
   int nranks, me;
-  unsigned long long klo, khi;
+  int nown;                                   // this rank's own pieces of the curve
+  const unsigned long long *ownlo, *ownhi;
 };
 
 // smallest possible squared distance between the point s and any point of the group's box
@@ -522,7 +607,7 @@ k_let_level(int nelem, int level, const int4 *__restrict__ lk, const double4 *__
           const unsigned long long ph = d_peano_of_morton(skey[me.z]);
           const unsigned long long lo = (ph >> sh) << sh;
           const unsigned long long hi = lo + (1ULL << sh);
-          shared = !(lo >= K.klo && hi <= K.khi);
+          shared = !d_owned_range(lo, hi, K.nown, K.ownlo, K.ownhi);
         }
       m4 = xm[e];
       c4 = cl[e];
@@ -1010,7 +1095,7 @@ static int gravity_step(ghip_ctx *ctx)
           const double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);
           k_dd_check_range<<<cdiv(ctx->n, 256), 256, 0, st>>>(
             ctx->n, x, x + ctx->n, x + 2 * (size_t) ctx->n, ctx->corner[0], ctx->corner[1],
-            ctx->corner[2], fac, D.splits[D.rank], D.splits[D.rank + 1],
+            ctx->corner[2], fac, D.nown, P<unsigned long long>(D.ownlo), P<unsigned long long>(D.ownhi),
             ghip_errword(ctx, GHIP_ERRW_TREE));
         }
       GCHK(ghip_tree_build_impl(ctx));
@@ -1041,8 +1126,9 @@ static int gravity_step(ghip_ctx *ctx)
           K.unequal = D.gp.unequal_softenings || ctx->adaptive_gravsoft;
           K.nranks = P_;
           K.me = D.rank;
-          K.klo = D.splits[D.rank];
-          K.khi = D.splits[D.rank + 1];
+          K.nown = D.nown;
+          K.ownlo = P<unsigned long long>(D.ownlo);
+          K.ownhi = P<unsigned long long>(D.ownhi);
           unsigned long long all = (P_ >= 64) ? ~0ULL : ((1ULL << P_) - 1ULL);
           all &= ~(1ULL << D.rank);
           unsigned long long *reach = P<unsigned long long>(D.reach),
@@ -1297,8 +1383,9 @@ struct MigTable
 };
 struct MigSplits
 {
-  int nranks, me;
-  unsigned long long s[GHIP_MAXRANKS + 1];
+  int nseg, me;
+  const unsigned long long *key;   // [nseg + 1]
+  const int *owner;                // [nseg]
 };
 
 void ghip_field_info(int f, int *gas, int *ncomp, int *isint);   // api.hip
@@ -1328,16 +1415,17 @@ __global__ void k_mig_dest(int n, const double *__restrict__ x, const double *__
   // (clamped to the cube: a particle that left it goes to the owner of the boundary cell -- whose range
   // check then refuses it until the host has set a fresh extent, see d_cell21)
   const unsigned long long k = d_peano21(d_cell21(x[i], cx, fac), d_cell21(y[i], cy, fac), d_cell21(z[i], cz, fac));
-  int lo = 0, hi = S.nranks - 1;   // largest r with s[r] <= k
+  int lo = 0, hi = S.nseg - 1;   // largest s with key[s] <= k
   while(lo < hi)
     {
       int mid = (lo + hi + 1) >> 1;
-      if(S.s[mid] <= k)
+      if(S.key[mid] <= k)
         lo = mid;
       else
         hi = mid - 1;
     }
-  mask[i] = (lo == S.me) ? 0ULL : (1ULL << lo);
+  const int dest = S.owner[lo];
+  mask[i] = (dest == S.me) ? 0ULL : (1ULL << dest);
 }
 
 __global__ void k_mig_pack(int nrec, const int *__restrict__ list, int n, int ngas, MigTable T,
@@ -1471,10 +1559,10 @@ static int migrate_step(ghip_ctx *ctx)
       if(n > 0 && P_ > 1)
         {
           MigSplits S;
-          S.nranks = P_;
+          S.nseg = D.nseg;
           S.me = D.rank;
-          for(int r = 0; r <= P_; r++)
-            S.s[r] = D.splits[r];
+          S.key = P<unsigned long long>(D.segkey);
+          S.owner = P<int>(D.segowner);
           const double *x = P<double>(ctx->f[GHIP_F_POS]);
           const double fac = 1.0 / ctx->dlen * (double) (1ULL << GHIP_BITS);
           k_mig_dest<<<cdiv(n, 256), 256, 0, st>>>(n, x, x + n, x + 2 * (size_t) n, ctx->corner[0],
@@ -1703,7 +1791,7 @@ void ghip_dd_release(ghip_ctx *ctx)
                   &D.src_key, &D.src_lvl, &D.gh_mask, &D.gh_list, &D.gh_send, &D.gh_recv, &D.gsx,
                   &D.gsy, &D.gsz, &D.gsm, &D.gsh, &D.h0, &D.gas_tgt, &D.mig_mask, &D.mig_list,
                   &D.mig_send, &D.mig_recv, &D.mig_scan, &D.gas_src, &D.sk_send, &D.sk_all, &D.sk_part,
-                  &D.sk_parts, &D.sk_work, &D.pm_all};
+                  &D.sk_parts, &D.sk_work, &D.pm_all, &D.segkey, &D.segowner, &D.ownlo, &D.ownhi};
   for(DevBuf *b : bs)
     {
       if(b->p)

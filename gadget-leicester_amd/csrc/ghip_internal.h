@@ -151,6 +151,12 @@ struct DDState
   bool on = false;
   int rank = 0, nranks = 1;
   unsigned long long splits[GHIP_MAXRANKS + 1];   // Peano-Hilbert key range of rank r: [splits[r], splits[r+1])
+  // The general form (MULTIPLEDOMAINS > 1: a rank owns several pieces of the curve, domain.c:482-494,
+  // 1158-1215): nseg segments [segkey[s], segkey[s+1]) with their owners, adjacent segments of one
+  // owner merged; ownlo/ownhi = this rank's own pieces.  Device copies for the three kernels that ask
+  // "whose is this key" (range check, shared-cell test of the LET selection, migration).
+  int nseg = 0, nown = 0;
+  DevBuf segkey, segowner, ownlo, ownhi;
   void *nccl = nullptr;                           // ncclComm_t (ghip_comm.hip)
   // state machine
   int op = 0, phase = 0, walk = 0;

@@ -51,6 +51,7 @@ double CPU_Step_Treewalk = 0, CPU_Step_Treebuild = 0, CPU_Step_Density = 0, CPU_
 struct topnode_data *TopNodes = NULL;
 int NTopnodes = 0, NTopleaves = 0;
 int *DomainStartList = NULL, *DomainEndList = NULL;
+int *DomainTask = NULL;
 int N_gas_swallowed = 0, N_BH_swallowed = 0, N_dust_swallowed = 0;
 
 static ghip_ctx *Ctx = NULL;
@@ -2021,6 +2022,44 @@ static int dd_prepare(void)
       endrun(90002);
       return -1;
     }
+  if(DomainLen <= 0)
+    domain_findExtent();
+  if(chk(ghip_dd_set_domain(Ctx, DomainCorner, DomainCenter, DomainLen, All.ForceSoftening),
+         "ghip_dd_set_domain"))
+    return -1;
+  if(TopNodes && DomainTask && NTopnodes > 0 && NTopleaves > 0)
+    {
+      /* -DMULTIPLEDOMAINS > 1: the curve leaf by leaf (top-leaves are numbered along the curve,
+       * domain.c:1495-1509) with the rank that owns each (DomainTask[], domain.c:1208-1215) */
+      unsigned long long *keys = (unsigned long long *) malloc((size_t) (NTopleaves + 1) * sizeof(unsigned long long));
+      if(!keys)
+        {
+          endrun(90003);
+          return -1;
+        }
+      for(int l = 0; l <= NTopleaves; l++)
+        keys[l] = ~0ULL;
+      for(int i = 0; i < NTopnodes; i++)
+        if(TopNodes[i].Daughter == -1 && TopNodes[i].Leaf >= 0 && TopNodes[i].Leaf < NTopleaves)
+          keys[TopNodes[i].Leaf] = TopNodes[i].StartKey;
+      int bad = 0;
+      for(int l = 0; l < NTopleaves; l++)
+        if(keys[l] == ~0ULL || (l > 0 && keys[l] < keys[l - 1]) || DomainTask[l] < 0 || DomainTask[l] >= NTask)
+          bad = 1;
+      keys[0] = 0;
+      keys[NTopleaves] = 1ULL << (3 * BITS_PER_DIMENSION);
+      int rc = bad ? GHIP_EINVAL : ghip_dd_set_segments(Ctx, NTopleaves, keys, DomainTask);
+      free(keys);
+      if(bad)
+        {
+          snprintf(ErrBuf, sizeof(ErrBuf), "TopNodes / DomainTask do not describe %d top-leaves along the curve "
+                   "owned by ranks 0..%d", NTopleaves, NTask - 1);
+          fprintf(stderr, "gadget_force: %s\n", ErrBuf);
+          endrun(90002);
+          return -1;
+        }
+      return chk(rc, "ghip_dd_set_segments") ? -1 : 0;
+    }
   if(!TopNodes || !DomainStartList || NTopnodes <= 0)
     {
       snprintf(ErrBuf, sizeof(ErrBuf), "NTask = %d: TopNodes / DomainStartList of the host's domain "
@@ -2029,11 +2068,6 @@ static int dd_prepare(void)
       endrun(90002);
       return -1;
     }
-  if(DomainLen <= 0)
-    domain_findExtent();
-  if(chk(ghip_dd_set_domain(Ctx, DomainCorner, DomainCenter, DomainLen, All.ForceSoftening),
-         "ghip_dd_set_domain"))
-    return -1;
   unsigned long long splits[GHIP_DD_MAXRANKS_HOST + 1];
   for(int r = 0; r < NTask; r++)
     {

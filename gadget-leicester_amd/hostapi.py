@@ -126,7 +126,7 @@ EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
            "density_evaluate", "hydro_evaluate", "ngb_treefind_variable", "ngb_treefind_pairs",
            "peano_hilbert_key", "morton_key", "hubble_function",
            "P", "SphP", "All", "NumPart", "N_gas", "FirstActiveParticle", "NextActiveParticle",
-           "TreeReconstructFlag", "DomainCorner", "DomainCenter", "DomainLen", "DomainFac",
+           "DomainTask", "TreeReconstructFlag", "DomainCorner", "DomainCenter", "DomainLen", "DomainFac",
            "Ngblist", "GravDataGet", "GravDataResult",
            "advance_and_find_timesteps", "find_dt_displacement_constraint", "get_timestep_bin",
            "gadget_force_set_kick_tables", "TimeBinCount", "TimeBinCountSph", "TimeBinActive",
@@ -249,9 +249,10 @@ class Host:
         self._agcb = HOST_ALLGATHER_CB(cb)
         self.L.gadget_force_set_allgather(self._agcb, None)
 
-    def set_topnodes(self, start_keys, sizes, start_list, end_list):
+    def set_topnodes(self, start_keys, sizes, start_list, end_list, domain_task=None):
         """the host's domain decomposition as the drivers read it: top-leaves in key order and the
-        leaf ranges of the ranks (TopNodes / DomainStartList / DomainEndList, allvars.h:424-449)"""
+        leaf ranges of the ranks (TopNodes / DomainStartList / DomainEndList, allvars.h:424-449);
+        domain_task: DomainTask[] per leaf (-DMULTIPLEDOMAINS > 1)"""
         nleaf = len(start_keys)
         arr = (TopNode * nleaf)()
         for i in range(nleaf):
@@ -265,6 +266,8 @@ class Host:
         self._seti("NTopleaves", nleaf)
         self._setp("DomainStartList", self._dstart)
         self._setp("DomainEndList", self._dend)
+        self._dtask = None if domain_task is None else np.ascontiguousarray(domain_task, np.int32)
+        self._setp("DomainTask", self._dtask)
 
     def close(self):
         self.L.gadget_force_bind_all(None, None)
@@ -272,6 +275,7 @@ class Host:
         self.L.gadget_force_set_allgather(C.cast(None, HOST_ALLGATHER_CB), None)
         self._seti("ThisTask", 0)
         self._seti("NTask", 1)
+        C.c_void_p.in_dll(self.L, "DomainTask").value = None
         self.L.gadget_force_finalize()
 
     def _setp(self, name, arr):

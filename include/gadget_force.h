@@ -417,6 +417,9 @@ struct topnode_data   /* allvars.h:437-447 */
 extern struct topnode_data *TopNodes;
 extern int NTopnodes, NTopleaves;
 extern int *DomainStartList, *DomainEndList;
+extern int *DomainTask;   /* allvars.h:429: the rank of every top-leaf.  When set (-DMULTIPLEDOMAINS > 1: a rank
+                             owns several pieces of the curve, domain.c:1158-1215) the drivers take the
+                             ownership of the curve from it, leaf by leaf, instead of from DomainStartList */
 int gadget_force_unique_id(void *id128);
 int gadget_force_connect(const void *id128);
 void gadget_force_set_allgather(int (*allgather)(void *user, const void *send, size_t bytes, void *recv),

@@ -336,6 +336,13 @@ int ghip_dd_set_domain(ghip_ctx *ctx, const double DomainCorner[3], const double
 /* nranks+1 Peano-Hilbert keys (21 bits per dimension): rank r owns [splits[r], splits[r+1]);
  * splits[0] = 0, splits[nranks] = 2^63.  Every resident particle must lie in its rank's range. */
 int ghip_dd_set_splits(ghip_ctx *ctx, const unsigned long long *splits);
+/* The general form, for decompositions in which a rank owns several pieces of the curve
+ * (-DMULTIPLEDOMAINS > 1, domain.c:482-494, 1158-1215: DomainTask[] per top-leaf): nseg segments
+ * [keys[s], keys[s+1]) in key order with owner[s]; keys[0] = 0, keys[nseg] = 2^63.  Neighbouring
+ * segments of one owner are merged.  A tree cell is "wholly this rank's" when it lies inside ONE of
+ * its pieces; everything else works as for one range per rank (the target groups of a rank then
+ * span its pieces, which only makes their boxes less compact). */
+int ghip_dd_set_segments(ghip_ctx *ctx, int nseg, const unsigned long long *keys, const int *owner);
 /* Peano-Hilbert keys of the resident particles (host array of numpart entries) */
 int ghip_dd_keys(ghip_ctx *ctx, unsigned long long *keys_host);
 /* domain_findSplit_work_balanced (domain.c:1075-1113, equal speed factors): cut ndomain

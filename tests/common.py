@@ -177,7 +177,7 @@ class ShardSet:
     its own (several logical shards on one GPU): the multi-GPU path as the parity tests drive it.
     Local particle order of a shard: its gas particles first (allvars.h:1384), global order kept."""
 
-    def __init__(self, pr, nshards, work=None, dev=0, fields=None):
+    def __init__(self, pr, nshards, work=None, dev=0, fields=None, domains=1):
         B = bindings()
         sh = importlib.import_module("gadget-leicester_amd.sharded")
         self.pr, self.P, self.B = pr, nshards, B
@@ -195,7 +195,21 @@ class ShardSet:
         sample = np.arange(0, pr.n, max(1, pr.n // 512))
         want = np.array([O.peano_hilbert_key(*ip[i]) for i in sample], dtype=np.uint64)
         assert np.array_equal(self.keys[sample], want), "device Peano-Hilbert keys differ"
-        self.splits, self.owner = sh.decompose(self.keys, nshards, work)
+        self.segments = None
+        if domains > 1:
+            # -DMULTIPLEDOMAINS=domains (the shipped Makefile: 16): the curve is cut into
+            # nshards * domains pieces and every shard owns `domains` of them -- here dealt out in
+            # turn, so that no two neighbouring pieces share an owner (domain.c:1158-1215 assigns them
+            # by load; any assignment is a valid decomposition)
+            pieces, piece_of = sh.decompose(self.keys, nshards * domains, work)
+            seg_owner = (np.arange(nshards * domains) * 7 + 3) % nshards if nshards % 7 else \
+                np.arange(nshards * domains) % nshards
+            seg_owner = seg_owner.astype(np.int32)
+            self.segments = (pieces, seg_owner)
+            self.splits = None
+            self.owner = seg_owner[piece_of].astype(np.int32)
+        else:
+            self.splits, self.owner = sh.decompose(self.keys, nshards, work)
         self.gid, self.ngas, self.fp = [], [], []
         extra = fields or {}
         for r in range(nshards):
@@ -223,7 +237,10 @@ class ShardSet:
                 fp.set_field(B.F_DTENTROPY, pr.dtentropy[gg])
             fp.dd_init(r, nshards)
             fp.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
-            fp.dd_set_splits(self.splits)
+            if self.segments is not None:
+                fp.dd_set_segments(*self.segments)
+            else:
+                fp.dd_set_splits(self.splits)
             self.fp.append(fp)
         self.run = sh.DomainShards(self.fp)
 

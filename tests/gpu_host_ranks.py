@@ -4,7 +4,8 @@ torch.distributed.run, one process per rank, all ranks on GPU 0.
 Every rank builds the same seeded problem, keeps the particles of its Peano-Hilbert key range as
 536 / 264-byte records (the shipped bundle's layout, bound by byte offsets), describes the
 decomposition the way domain_Decomposition leaves it (TopNodes[] leaves in key order,
-DomainStartList / DomainEndList per rank) and calls accel.c's sequence through the reference-named
+DomainStartList / DomainEndList, and DomainTask[] per leaf: every rank owns FOUR pieces of the curve,
+-DMULTIPLEDOMAINS=4) and calls accel.c's sequence through the reference-named
 symbols of libgadget_force.so with NTask = world size: gravity_tree() x 2, density() -- gas, sinks
 and dust grains --, force_update_hmax(), hydro_force(), then the neighbour passes of
 blackhole_accretion().  Exchanges go through the host's all-gather (gloo).  Rank 0 gathers the
@@ -57,10 +58,19 @@ def main():
     shift = np.uint64(63 - 3 * level)
     cell = (keys >> shift).astype(np.int64)
     hist = np.bincount(cell, minlength=8 ** level).astype(np.float64)
-    start, end = B.dd_find_split(world, hist)
+    # -DMULTIPLEDOMAINS=4 (the shipped Makefile sets 16): the curve is cut into 4 * NTask pieces, dealt out
+    # to the ranks in turn (domain.c:1158-1215 assigns them by load); DomainTask[] tells the drivers
+    md = 4
+    start, end = B.dd_find_split(world * md, hist)
     leaf_keys = (np.arange(8 ** level, dtype=np.uint64) << shift)
     leaf_size = np.full(8 ** level, np.uint64(1) << shift, np.uint64)
-    owner = np.searchsorted(np.asarray(start[1:], np.int64), cell, side="right")
+    piece = np.searchsorted(np.asarray(start[1:], np.int64), np.arange(8 ** level), side="right")
+    piece_task = (np.arange(world * md) % world).astype(np.int32)
+    domain_task = piece_task[piece].astype(np.int32)           # per top-leaf
+    owner = domain_task[cell]
+    # DomainStartList / DomainEndList in the reference's layout [task * MULTIPLEDOMAINS + m]
+    order = np.argsort(piece_task, kind="stable")
+    start, end = np.asarray(start, np.int32)[order], np.asarray(end, np.int32)[order]
     mine = np.where(owner == rank)[0]
     gid = np.concatenate([mine[mine < ng], mine[mine >= ng]])
 
@@ -81,7 +91,7 @@ def main():
         host.set_allgather(allgather)
         host.bind_records(P, Sp, lay, bh)
         TB.set_all(host, sp, eps)
-        host.set_topnodes(leaf_keys, leaf_size, start, end)
+        host.set_topnodes(leaf_keys, leaf_size, start, end, domain_task=domain_task)
         host.set_active(None)
         host.domain()            # the extent of ALL ranks (domain.c:1996-1997)
         L = host.L

@@ -671,3 +671,84 @@ def test_hydro_release_variants_do_the_same_work():
                                        "hydro_pairs")})
     assert work[0]["hydro_pairs"] > 0 and work[0]["ewald_interactions"] > 0
     assert work[1] == work[0] and work[2] == work[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshards,domains", [(3, 4), (4, 16)])
+def test_shards_that_own_several_pieces_of_the_curve(nshards, domains):
+    """-DMULTIPLEDOMAINS > 1 (the shipped Makefile sets 16): a rank owns several disjoint pieces of the
+    Peano-Hilbert curve (domain.c:482-494, 1158-1215), given as segments with owners
+    (ghip_dd_set_segments).  A tree cell is a shard's own only when it lies inside ONE of its pieces;
+    the target groups of a shard span its pieces.  Everything else is the one-range path: gravity
+    counts exact against the single global tree, density / hydro to rounding, and a migration after a
+    shake sends every particle to the owner of the piece its new key falls into."""
+    B = bindings()
+    pr = Problem(ng=12, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    S = ShardSet(pr, nshards, domains=domains)
+    try:
+        pieces, seg_owner = S.segments
+        assert len(seg_owner) == nshards * domains and len(np.unique(seg_owner)) == nshards
+        assert np.all(seg_owner[1:] != seg_owner[:-1])               # no two neighbours merge
+        sizes = [len(g) for g in S.gid]
+        assert sum(sizes) == n and min(sizes) > 0
+        T = pr.oracle_tree()
+        tg = np.arange(n, dtype=np.int32)
+        tab = O.ewald_table(pr.box)
+        S.run.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
+        a0, c0 = T.gravity(pr.o_grav(pr.theta), tg, np.zeros(n))
+        T.gravity_ewald_add(pr.o_grav(pr.theta), tab, tg, np.zeros(n), a0, c0)
+        assert np.array_equal(S.get_field(B.F_GRAVCOST), c0)
+        assert relerr(S.get_field(B.F_GRAVACCEL), a0) < TOL
+        old = np.linalg.norm(a0, axis=1)
+        S.set_field(B.F_OLDACC, old)
+        S.run.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+        a1, c1 = T.gravity(pr.o_grav(0.0), tg, old)
+        T.gravity_ewald_add(pr.o_grav(0.0), tab, tg, old, a1, c1)
+        assert np.array_equal(S.get_field(B.F_GRAVCOST), c1)
+        assert relerr(S.get_field(B.F_GRAVACCEL), a1) < TOL
+        info = S.each(lambda fp: fp.dd_info())
+        assert all(i["let_imported"] > 0 for i in info)
+        # SPH through the ghosts
+        S.run.density(pr.g_dens())
+        S.each(lambda fp: fp.update_hmax())
+        S.run.hydro(pr.g_hydro())
+        act = np.arange(ng, dtype=np.int32)
+        od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin,
+                       pr.ti_begstep, pr.hsml0)
+        assert relerr(S.get_field(B.F_HSML)[:ng], od["hsml"][:ng]) < TOL
+        assert relerr(S.get_field(B.F_DENSITY), od["density"][:ng]) < TOL
+        T.update_hmax(act, od["hsml"], od["divvel"])
+        oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"],
+                     od["dhsmlfac"], od["divvel"], od["curlvel"], pr.timebin)
+        st = S.each(lambda fp: fp.stats())
+        assert sum(s["hydro_pairs"] for s in st) == oh["npairs"]
+        ha = S.get_field(B.F_HYDROACCEL)
+        assert np.abs(ha - oh["hydroaccel"][:ng]).max() < TOL * np.abs(oh["hydroaccel"]).max()
+        # migration: shake the particles inside the cube, everybody to the owner of its new piece
+        rng = np.random.default_rng(3)
+        lo, ln = pr.extent[0], pr.extent[2]
+        newpos = np.clip(pr.ic["pos"] + 0.02 * pr.box * rng.standard_normal((n, 3)), lo + 1e-9 * ln,
+                         lo + ln * (1 - 1e-9))
+        S.set_field(B.F_POS, newpos)
+        S.migrate()
+        probe = B.ForcePath(0)
+        probe.set_counts(n, 0)
+        probe.set_field(B.F_POS, newpos)
+        probe.dd_init(0, 1)
+        probe.dd_set_domain(pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+        keys = probe.dd_keys()
+        probe.close()
+        want_owner = seg_owner[np.searchsorted(pieces[1:-1], keys, side="right")]
+        assert np.array_equal(S.owner, want_owner)
+        assert sum(len(g) for g in S.gid) == n and (want_owner != seg_owner[np.searchsorted(
+            pieces[1:-1], S.keys, side="right")]).sum() > 10
+        # and the forces on the re-sharded set are again the single tree's
+        T2 = O.Tree(newpos, pr.ic["vel"], pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0,
+                    extent=pr.extent)
+        S.run.gravity(pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
+        a2, c2 = T2.gravity(pr.o_grav(0.0), tg, old)
+        T2.gravity_ewald_add(pr.o_grav(0.0), tab, tg, old, a2, c2)
+        assert np.array_equal(S.get_field(B.F_GRAVCOST), c2)
+    finally:
+        S.close()
