@@ -38,7 +38,7 @@ int FirstInTimeBin[TIMEBINS], LastInTimeBin[TIMEBINS];
 int *NextInTimeBin, *PrevInTimeBin;
 int Flag_FullStep;
 static double dt_displacement = 0; /* timestep.c:17 */
-static const double *KickTabGrav, *KickTabHydro;
+static const double *KickTabGrav, *KickTabHydro, *DriftTab;
 static double KickLogBegin, KickLogMax;
 double DomainCorner[3], DomainCenter[3], DomainLen = 0, DomainFac = 0;
 int *Ngblist = NULL;
@@ -295,7 +295,7 @@ void gadget_force_finalize(void)
   Nextnode = Father = NULL;
   MaxNodes = Numnodestree = 0;
   NextInTimeBin = PrevInTimeBin = NULL;
-  KickTabGrav = KickTabHydro = NULL;
+  KickTabGrav = KickTabHydro = DriftTab = NULL;
   dt_displacement = 0;
 }
 
@@ -809,6 +809,8 @@ void ewald_init(void)
   chk(ghip_ewald_init(Ctx, All.BoxSize), "ghip_ewald_init");
 }
 
+static double drift_factor(int time0, int time1);
+
 static int ensure_tree_split(int split)
 {
   if(!DeviceFresh)
@@ -821,10 +823,12 @@ static int ensure_tree_split(int split)
       /* gravtree.c:60-70.  cfg.dynamic_tree and no reconstruction asked for: the tree of the last
        * force_treebuild() goes to the current time (force_drift_node for every node, the kicks
        * recorded since folded in) and the walks read it */
-      if(Cfg.dynamic_tree && !TreeReconstructFlag && KeptTree && KeptN == NumPart && !All.ComovingIntegrationOn &&
-         NTask == 1)
+      if(Cfg.dynamic_tree && !TreeReconstructFlag && KeptTree && KeptN == NumPart && NTask == 1 &&
+         (!All.ComovingIntegrationOn || (DriftTab && KickLogMax > KickLogBegin)))
         {
-          const double dt_drift = (All.Ti_Current - KeptTi) * All.Timebase_interval;   /* forcetree.c:1414 */
+          /* forcetree.c:1403-1425 */
+          const double dt_drift = All.ComovingIntegrationOn ? drift_factor(KeptTi, All.Ti_Current)
+                                                            : (All.Ti_Current - KeptTi) * All.Timebase_interval;
           if(chk(ghip_tree_substep(Ctx, dt_drift), "ghip_tree_substep"))
             return -1;
           KeptTi = All.Ti_Current;
@@ -1286,6 +1290,33 @@ void hydro_force(void)
 /* ------------------------------------------------------------------------------------------
  * "next" row N1: timestep criterion + kick
  * ---------------------------------------------------------------------------------------- */
+/* driftfac.c:123-163 get_drift_factor on the host's DriftTable (cfg.dynamic_tree in comoving runs:
+ * force_drift_node's dt_drift, forcetree.c:1403-1412).  DRIFT_TABLE_LENGTH = 1000 (driftfac.c:12). */
+void gadget_force_set_drift_table(const double *drifttable)
+{
+  DriftTab = drifttable;
+}
+
+static double drift_factor(int time0, int time1)
+{
+  const int len = 1000;
+  double u[2], df[2];
+  const int t[2] = { time0, time1 };
+  for(int k = 0; k < 2; k++)
+    {
+      double a = KickLogBegin + t[k] * All.Timebase_interval;
+      u[k] = (a - KickLogBegin) / (KickLogMax - KickLogBegin) * len;
+      int i = (int) u[k];
+      if(i >= len)
+        i = len - 1;
+      if(i <= 1)
+        df[k] = u[k] * DriftTab[0];
+      else
+        df[k] = DriftTab[i - 1] + (DriftTab[i] - DriftTab[i - 1]) * (u[k] - i);
+    }
+  return df[1] - df[0];
+}
+
 void gadget_force_set_kick_tables(const double *gravkick, const double *hydrokick,
                                   double logTimeBegin, double logTimeMax)
 {

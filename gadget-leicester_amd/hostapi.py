@@ -120,7 +120,7 @@ EXPORTS = ["gadget_force_bind_all", "gadget_force_all_layout_count",
            "gadget_force_ctx", "gadget_force_layout", "gadget_force_set_endrun",
            "gadget_force_mark_dirty", "endrun", "set_softenings", "data_index_compare",
            "mysort_dataindex", "domain_findExtent",
-           "force_treebuild", "force_kick_node", "force_finish_kick_nodes", "ewald_init", "gravity_tree", "density", "density_isactive",
+           "gadget_force_set_drift_table", "force_treebuild", "force_kick_node", "force_finish_kick_nodes", "ewald_init", "gravity_tree", "density", "density_isactive",
            "force_update_hmax", "hydro_force", "force_treeevaluate",
            "force_treeevaluate_shortrange", "force_treeevaluate_ewald_correction",
            "density_evaluate", "hydro_evaluate", "ngb_treefind_variable", "ngb_treefind_pairs",

@@ -287,7 +287,8 @@ struct gadget_force_config
                               current positions.  force_kick_node() and force_finish_kick_nodes() below
                               are then the reference's (timestep.c:261, 588); the library's own
                               advance_and_find_timesteps() hands its kicks to the nodes itself.
-                              Non-comoving runs; 0 (default): every gravity_tree() rebuilds */
+                              Comoving runs need gadget_force_set_drift_table(); 0 (default): every
+                              gravity_tree() rebuilds */
   int pin_records;         /* 1: page-lock the first NumPart / N_gas records of P[] / SphP[] when they
                               are first uploaded (again when the arrays move or grow), so the record
                               copies run at the link's rate; released by gadget_force_finalize().  The
@@ -337,6 +338,10 @@ void gadget_force_set_endrun(void (*handler)(int code));
 /* the comoving kick-factor tables of driftfac.c (GravKickTable / HydroKickTable, 1000 entries each,
  * built by the host's init_drift_table) and their log(a) range; needed when
  * All.ComovingIntegrationOn is set */
+/* the host's DriftTable[DRIFT_TABLE_LENGTH] (driftfac.c:26-60): cfg.dynamic_tree in comoving runs takes
+ * force_drift_node's dt_drift from it (get_drift_factor, driftfac.c:123-163; logTimeBegin / logTimeMax
+ * as given to gadget_force_set_kick_tables); without it a comoving sub-step rebuilds */
+void gadget_force_set_drift_table(const double *drifttable);
 void gadget_force_set_kick_tables(const double *gravkick, const double *hydrokick,
                                   double logTimeBegin, double logTimeMax);
 /* tell the glue that the host changed P/SphP outside the four drivers */
