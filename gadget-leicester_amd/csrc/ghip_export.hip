@@ -434,7 +434,8 @@ int ghip_dyn_kick_recorded(ghip_ctx *ctx)
   return dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag));
 }
 
-// (a particle kicked twice at one sync point -- gravity, then a feedback kick -- hands up the sum)
+// (a particle kicked twice at one sync point -- gravity, then a feedback kick -- hands up the sum of
+// its kicks and the largest of its |Vel|: the rows were cleared, every entry adds)
 __global__ void k_dyn_scatter_kicks(int nk, int n, const int *__restrict__ idx, const double *__restrict__ dv3,
                                     const double *__restrict__ vmaxk, double *__restrict__ dv,
                                     int *__restrict__ flag)
@@ -445,16 +446,12 @@ __global__ void k_dyn_scatter_kicks(int nk, int n, const int *__restrict__ idx, 
   int i = idx[k];
   if(i < 0 || i >= n)
     return;
-  const bool first = atomicExch(&flag[i], 1) == 0;
+  flag[i] = 1;
   for(int j = 0; j < 3; j++)
-    {
-      if(first)
-        dv[(size_t) j * n + i] = dv3[3 * (size_t) k + j];
-      else
-        atomicAdd(&dv[(size_t) j * n + i], dv3[3 * (size_t) k + j]);
-    }
-  if(vmaxk)
-    dv[3 * (size_t) n + i] = vmaxk[k];   // (the later entry of a particle carries its final velocity)
+    atomicAdd(&dv[(size_t) j * n + i], dv3[3 * (size_t) k + j]);
+  if(vmaxk)   // (non-negative doubles order like their bit patterns)
+    atomicMax(reinterpret_cast<unsigned long long *>(&dv[3 * (size_t) n + i]),
+              (unsigned long long) __double_as_longlong(vmaxk[k]));
 }
 
 static int kick_nodes_host(ghip_ctx *ctx, int nkicked, const int *idx, const double *dv3, const double *vmaxk);
@@ -495,6 +492,7 @@ static int kick_nodes_host(ghip_ctx *ctx, int nkicked, const int *idx, const dou
   if(vmaxk)
     HIPCHK(hipMemcpyAsync(dvm, vmaxk, (size_t) nkicked * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(ctx->kick_flag.p, 0, n * 4, st));
+  HIPCHK(hipMemsetAsync(ctx->kick_dv.p, 0, 4 * n * 8, st));
   k_dyn_scatter_kicks<<<cdiv(nkicked, 256), 256, 0, st>>>(nkicked, ctx->n, didx, ddv, vmaxk ? dvm : nullptr,
                                                           P<double>(ctx->kick_dv), P<int>(ctx->kick_flag));
   GCHK(dyn_kick_pass(ctx, P<double>(ctx->kick_dv), P<int>(ctx->kick_flag),

@@ -725,6 +725,12 @@ static int pair_balance(ghip_ctx *ctx)
   else if(ctx->pc_cost[oth] < ctx->pc_cost[cur])
     want = oth;
   ctx->pair_lds = want ? 10240 : 8192;
+  static int dbg = -1;
+  if(dbg < 0)
+    dbg = getenv("GHIP_PAIR_DEBUG") ? 1 : 0;
+  if(dbg)
+    fprintf(stderr, "[pair_balance] cost 8K %.3f (age %d)  10K %.3f (age %d)  -> %d\n", ctx->pc_cost[0],
+            ctx->pc_age[0], ctx->pc_cost[1], ctx->pc_age[1], ctx->pair_lds);
   return GHIP_OK;
 }
 

@@ -272,6 +272,7 @@ void gadget_force_finalize(void)
   PinPBytes = PinSBytes = 0;
   free(KickIdx);
   free(KickDv);
+  free(KickVmax);
   KickIdx = NULL;
   KickDv = KickVmax = NULL;
   KickN = KickCap = 0;
@@ -849,21 +850,21 @@ void force_kick_node(int i, MyFloat *dv)
     return;
   if(KickN >= KickCap)
     {
-      int nc = KickCap ? 2 * KickCap : 4096;
+      const int nc = KickCap ? 2 * KickCap : 4096;
       int *ni = (int *) realloc(KickIdx, (size_t) nc * sizeof(int));
       if(ni)
         KickIdx = ni;
-      double *nd = (double *) realloc(KickDv, (size_t) nc * 4 * sizeof(double));
-      if(!ni || !nd)
+      double *nd = (double *) realloc(KickDv, (size_t) nc * 3 * sizeof(double));
+      if(nd)
+        KickDv = nd;
+      double *nv = (double *) realloc(KickVmax, (size_t) nc * sizeof(double));
+      if(nv)
+        KickVmax = nv;
+      if(!ni || !nd || !nv)
         {
           endrun(90003);
           return;
         }
-      /* (layout [cap][3] dv, then [cap] vmax: re-pack the old entries behind the grown dv block) */
-      if(KickN > 0)
-        memmove(nd + 3 * (size_t) nc, nd + 3 * (size_t) KickCap, (size_t) KickN * sizeof(double));
-      KickDv = nd;
-      KickVmax = nd + 3 * (size_t) nc;
       KickCap = nc;
     }
   KickIdx[KickN] = i;
