@@ -679,8 +679,8 @@ static int combine_walk(ghip_ctx *ctx, const WalkJob &J, int nt, const int *tgt,
 // per SIMD or 10 KB = 4 per SIMD -- the allocation granularity leaves nothing in between.  Which one
 // is better depends on the workload, so it is measured: every pair records its walks' start / end
 // events together with the setting it ran under; finished pairs are read back here (never waited
-// for) and cost max(Newtonian, 1.1 x Ewald) -- the hydro kernel, about a tenth of the Ewald walk,
-// can only start when the Ewald walk drains.  The cheaper setting is used; the other one is tried
+// for) and cost max(Newtonian, Ewald), or max(Newtonian, 1.1 x Ewald) when the hydro kernel was
+// queued underneath the pair -- about a tenth of the Ewald walk, it can only start when that walk drains.  The cheaper setting is used; the other one is tried
 // again for one measurement every 64 pairs.  Scheduling only: the sums of a launch do not depend on it.
 static int pair_balance(ghip_ctx *ctx)
 {
@@ -706,7 +706,9 @@ static int pair_balance(ghip_ctx *ctx)
       if(hipEventElapsedTime(&tn, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&te, e[2], e[3]) == hipSuccess)
         {
           const int k = ctx->pc_cap[i] > 8192 ? 1 : 0;
-          const float c = tn > 1.1f * te ? tn : 1.1f * te;
+          // (only a hydro kernel that waits underneath the pair lengthens the Ewald side)
+          const float fe = ctx->pc_hyd[i] ? 1.1f : 1.0f;
+          const float c = tn > fe * te ? tn : fe * te;
           ctx->pc_cost[k] = c;
           ctx->pc_age[k] = 0;
         }
@@ -720,7 +722,11 @@ static int pair_balance(ghip_ctx *ctx)
   if(ctx->pc_cost[cur] < 0)
     return GHIP_OK;   // nothing known about the setting in use yet: keep it
   int want = cur;
-  if(ctx->pc_cost[oth] < 0 || ctx->pc_age[oth] > 64)
+  // (a measurement of the other setting goes stale: after 64 pairs, after 16 when the two are within
+  // 10 % of each other -- the first pairs of a run are not representative, their plans have no history)
+  const bool close = ctx->pc_cost[oth] > 0 && ctx->pc_cost[oth] < 1.1f * ctx->pc_cost[cur] &&
+                     ctx->pc_cost[cur] < 1.1f * ctx->pc_cost[oth];
+  if(ctx->pc_cost[oth] < 0 || ctx->pc_age[oth] > (close ? 16 : 64))
     want = oth;       // (stays there until a pair under it has been measured)
   else if(ctx->pc_cost[oth] < ctx->pc_cost[cur])
     want = oth;
@@ -801,6 +807,7 @@ int ghip_gravity_impl(ghip_ctx *ctx, const ghip_grav_params *p, int walk)
   GCHK(pair_balance(ctx));
   hipEvent_t *pc = ctx->pc_ev[ctx->pc_head];
   ctx->pc_cap[ctx->pc_head] = ctx->pair_lds;
+  ctx->pc_hyd[ctx->pc_head] = 0;
   ctx->pc_head = (ctx->pc_head + 1) & 3;
   HIPCHK(hipEventRecord(pc[0], sN));
   GCHK(run_walk(ctx, A, nt, tgt, sN));

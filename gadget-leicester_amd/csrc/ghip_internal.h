@@ -367,6 +367,7 @@ struct ghip_ctx
   int pair_lds = 10240;
   hipEvent_t pc_ev[4][4] = {};
   int pc_cap[4] = {0, 0, 0, 0};        // 0: slot empty or already read
+  int pc_hyd[4] = {0, 0, 0, 0};        // the hydro kernel was queued underneath that pair
   int pc_head = 0;
   bool pc_ready = false;
   float pc_cost[2] = {-1.f, -1.f};     // last measured cost of a pair under 8 KB / 10 KB

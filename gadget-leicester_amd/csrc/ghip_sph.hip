@@ -1299,6 +1299,8 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
   // the kernel's end event instead).
   // (ghip_set_hydro_release(ctx, 1): at once -- for a host whose download of the SPH results then also
   // runs underneath the walks, which is worth more than the 0.2 ms)
+  if(ctx->grav_pending)
+    ctx->pc_hyd[(ctx->pc_head + 3) & 3] = 1;   // (the pair launched last: its cost includes this kernel)
   if(ctx->grav_pending && !ctx->hydro_early && !getenv("GHIP_HYDRO_EARLY"))
     {
       static int drain = -1;

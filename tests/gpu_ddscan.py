@@ -55,7 +55,7 @@ def main():
         run_op(S, B.DD_GRAVITY, pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
         S.each(lambda fp: fp.gravity_finish(pr.G))
         run_op(S, B.DD_DENSITY, pr.g_dens())
-        for rep in range(int(os.environ.get("DDSCAN_REPS", "4"))):   # (the pair's balance settles within three pairs)
+        for rep in range(int(os.environ.get("DDSCAN_REPS", "20"))):   # (the pair's balance needs a re-probe of the other setting, 16 pairs)
             mig = run_op(S, B.DD_MIGRATE, None)
             g = run_op(S, B.DD_GRAVITY, pr.g_grav(0.0), B.WALK_NEWTON_EWALD)
             d = run_op(S, B.DD_DENSITY, pr.g_dens())
