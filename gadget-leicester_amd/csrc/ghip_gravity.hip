@@ -271,7 +271,9 @@ static int prepare_tables(ghip_ctx *ctx, const ghip_grav_params *p, int walk, Gr
   // XCD-contiguous block order: off by default -- with the adaptive plan the grid is sized for
   // the worst case and its idle tail would all land on the last XCD (measured: Ewald walk 8.4 vs
   // 7.7 ms); the L2 locality it buys was within noise (12.9 vs 13.1 ms)
-  k.xcd_remap = (getenv("GHIP_WALK_XCD") && atoi(getenv("GHIP_WALK_XCD")) == 1) ? 1 : 0;
+  k.xcd_remap = getenv("GHIP_WALK_XCD") ? atoi(getenv("GHIP_WALK_XCD")) : 0;
+  if(k.xcd_remap < 0)
+    k.xcd_remap = 0;
   if(walk == GHIP_WALK_SHORTRANGE)
     {
       if(!(p->Asmth > 0) || !(p->Rcut > 0))
@@ -531,6 +533,8 @@ static void launch_walk(ghip_ctx *ctx, const TreeDev &t, const WalkSeg &sg, int 
     }
   int blocks = cdiv(nthreads, bsize);
   blocks = (blocks + 7) & ~7;   // whole number of blocks per XCD (see k_grav_walk)
+  if(k.xcd_remap > 1)           // ... and of chunks per XCD, so that the chunked order covers every wavefront
+    blocks = ((blocks + 8 * k.xcd_remap - 1) / (8 * k.xcd_remap)) * (8 * k.xcd_remap);
   WalkPlan pl = plan;
   if(pl.started)
     {

@@ -818,8 +818,18 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
   // (hipStreamWaitValue32 in ghip_hydro) instead of for the kernel's end
   if(plan.started && blockIdx.x == plan.started_at && threadIdx.x == 0)
     __hip_atomic_store(plan.started, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // xcd_remap 1: XCD x walks the x-th eighth of the wavefront list; G > 1: the list is dealt to the XCDs
+  // in chunks of G consecutive wavefronts (XCD x takes chunks x, x + 8, ...): the buckets resident on an
+  // XCD are neighbours, the work is still spread evenly
   const int per_xcd = gridDim.x >> 3;
-  const int lblock = p.xcd_remap ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  int lblock = blockIdx.x;
+  if(p.xcd_remap == 1)
+    lblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  else if(p.xcd_remap > 1)
+    {
+      const int j = blockIdx.x >> 3, x = blockIdx.x & 7, G = p.xcd_remap;
+      lblock = ((j / G) * 8 + x) * G + (j % G);
+    }
   const int wave = __builtin_amdgcn_readfirstlane((lblock * (int) blockDim.x + threadIdx.x) >> 6);
   if(wave >= plan.nwaves)
     return;
