@@ -908,7 +908,10 @@ extern "C" int ghip_gravity_to_records(ghip_ctx *ctx, double G, int pmgrid, doub
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_to_records: null record pointer");
   if(ctx->aosP.cap < n * lay->p_stride)
     return ghip_fail(ctx, GHIP_EINVAL, "ghip_gravity_to_records: no device image (call ghip_upload_aos)");
-  const bool side = ctx->grav_pending;
+  // (records with Hsml in P[] carry SPH results in the same block: a download queued on the main
+  // stream could then copy the block with stale gravity fields over this one -- everything in order on
+  // the main stream for such layouts)
+  const bool side = ctx->grav_pending && lay->p_hsml < 0;
   hipStream_t st = ctx->stream;
   if(side)
     st = ctx->stream2;   // (the pair's last kernel, the Ewald sums' combine, is on this stream)
