@@ -360,8 +360,9 @@ def main():
             rows.append(("gravity: exchanges", sum(x)))
             c, x = dom.timed(B.DD_DENSITY, dp)
             names = ["density: gas groups", "density: ghost selection",
-                     "density: gas tree + h iteration", "density: refresh of the ghosts' hosts"]
-            rows += [(names[i] if i < 4 else "density: phase %d" % i, v) for i, v in enumerate(c)]
+                     "density: gas tree + h iteration", "density: growth check + refresh packing",
+                     "density: refresh of the ghosts"]
+            rows += [(names[i] if i < 5 else "density: phase %d" % i, v) for i, v in enumerate(c)]
             rows.append(("density: exchanges", sum(x)))
             fp.sync()
             t1 = time.perf_counter()
