@@ -2002,12 +2002,15 @@ def test_kicks_of_advance_timesteps_reach_the_nodes_of_the_kept_tree():
 
 
 @pytest.mark.gpu
-def test_gravity_tree_with_TreeReconstructFlag_zero_walks_the_kept_tree():
+@pytest.mark.parametrize("comoving", [0, 1])
+def test_gravity_tree_with_TreeReconstructFlag_zero_walks_the_kept_tree(comoving):
     """The host mirror with gadget_force_config.dynamic_tree (All.DoDynamicUpdate): after a full step
     (TreeReconstructFlag = 1) the host kicks an active subset itself and tells the tree through
     force_kick_node() / force_finish_kick_nodes() as timestep.c:261, 588 do, drifts everybody, and calls
     gravity_tree() with TreeReconstructFlag = 0: GravCost and GravAccel are those of the oracle's drifted
-    and kicked tree, not of a rebuild.  A later call with TreeReconstructFlag = 1 rebuilds."""
+    and kicked tree, not of a rebuild.  A later call with TreeReconstructFlag = 1 rebuilds.
+    comoving: the node drift takes get_drift_factor(Ti_tree, Ti_Current) from the host's DriftTable
+    (driftfac.c:123-163, forcetree.c:1403-1412) instead of (Ti_Current - Ti_tree) * Timebase_interval."""
     H = importlib.import_module("gadget-leicester_amd.hostapi")
     pr = Problem(ng=10, gas=False, periodic=1)
     n = pr.n
@@ -2019,6 +2022,29 @@ def test_gravity_tree_with_TreeReconstructFlag_zero_walks_the_kept_tree():
     c, ce, ln = pr.extent
     pr.extent = (c - 0.05 * ln, ce.copy(), 1.1 * ln)
     host.set_domain(*pr.extent)
+    drift_table = None
+    if comoving:
+        # a DriftTable as driftfac.c:26-60 fills it (any increasing table serves): logTimeBegin = 0,
+        # logTimeMax = 1, so that u = Ti * Timebase_interval * 1000 runs through the first few entries
+        drift_table = np.cumsum(0.8 + 0.4 * rng.random(1000)) * 1e-3
+        A_ = host.All
+        A_.ComovingIntegrationOn, A_.Time = 1, 1.0
+        for name in ("Gas", "Halo", "Disk", "Bulge", "Stars", "Bndry"):       # (no maximum physical softening)
+            setattr(A_, "Softening" + name + "MaxPhys", 1e30)
+        L.set_softenings()
+        L.gadget_force_set_kick_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        L.gadget_force_set_kick_tables(drift_table.ctypes.data, drift_table.ctypes.data, 0.0, 1.0)
+        L.gadget_force_set_drift_table.argtypes = [C.c_void_p]
+        L.gadget_force_set_drift_table(drift_table.ctypes.data)
+
+    def drift_factor(t0, t1):
+        u = np.array([t0, t1]) * host.All.Timebase_interval / 1.0 * 1000
+        df = []
+        for x in u:
+            i = min(int(x), 999)
+            df.append(x * drift_table[0] if i <= 1 else
+                      drift_table[i - 1] + (drift_table[i] - drift_table[i - 1]) * (x - i))
+        return df[1] - df[0]
     A = host.All
     tab = O.ewald_table(pr.box)
     everybody = np.arange(n, dtype=np.int32)
@@ -2051,7 +2077,7 @@ def test_gravity_tree_with_TreeReconstructFlag_zero_walks_the_kept_tree():
         T.vel[:] = P["Vel"]
         T.kick_nodes(act, dv)
         dti = 3 + step
-        dt = dti * A.Timebase_interval
+        dt = drift_factor(ti, ti + dti) if comoving else dti * A.Timebase_interval
         P["Pos"] += P["Vel"] * dt                            # everybody drifted to the sync point
         ti += dti
         A.Ti_Current = ti
