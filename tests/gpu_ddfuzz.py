@@ -3,6 +3,7 @@ distributions (clustered lattices, Plummer spheres, uniform noise), periodic / o
 / unequal softenings, 2..8 logical shards (some of them nearly or entirely empty), Barnes-Hut or
 relative criterion, pair or separate walks, SPH, a drift + migration -- shards against the oracle's
 single tree, counts exactly.   python tests/gpu_ddfuzz.py [nseeds] [first seed]"""
+import os
 import sys
 import time
 
@@ -47,7 +48,9 @@ def one(seed):
     if rng.random() < 0.3:                      # lopsided cuts: some shards (nearly) empty
         work = rng.random(n) ** 8
     old = 0.2 + 3.0 * rng.random(n)
-    S = ShardSet(pr, P, work=work, fields={"oldacc": old})
+    # -DMULTIPLEDOMAINS: every third problem gives each shard several pieces of the curve
+    domains = int(rng.choice([1, 1, 1, 2, 4])) if os.environ.get("DDFUZZ_DOMAINS", "1") == "1" else 1
+    S = ShardSet(pr, P, work=work, fields={"oldacc": old}, domains=domains)
     try:
         sizes = [len(g) for g in S.gid]
         tg = np.arange(n, dtype=np.int32)

@@ -1,7 +1,7 @@
 """Development aid: seeded random sweeps of the parity checks -- particle numbers, distributions
 (plane-wave clustered lattices, Plummer spheres, uniform noise), periodic / open boundaries, equal /
 unequal softenings, full and partial active lists -- device against the oracle, counts exactly.
-python tests/gpu_fuzz.py [nseeds]"""
+python tests/gpu_fuzz.py [nseeds] [first seed]"""
 import sys
 import time
 
@@ -98,14 +98,65 @@ def one(seed):
         want = oh["hydroaccel"][gas]
         assert fp.stats()["hydro_pairs"] == oh["npairs"], "pairs"
         assert np.abs(ha - want).max() <= 1e-10 * (np.abs(want).max() + 1e-300), "hydro"
-    return kind, n, ng, mode, unequal, adaptive, (None if act is None else len(act))
+    substeps = 0
+    if not adaptive and rng.random() < 0.4:
+        substeps = substep_sequence(rng, pr, periodic)
+    return kind, n, ng, mode, unequal, adaptive, (None if act is None else len(act)), substeps
+
+
+def substep_sequence(rng, pr, periodic):
+    """Sub-steps on the tree of the last full build (forcetree.c:1356-1520): random kicks of random
+    subsets, drifts of everybody, gravity for random active lists on the kept tree -- counts against the
+    oracle's drifted and kicked insertion tree."""
+    n = pr.n
+    c, ce, ln = pr.extent
+    ext = (c - 0.1 * ln, ce.copy(), 1.2 * ln)               # room to drift inside the domain cube
+    vel = pr.ic["vel"].copy()
+    vscale = np.abs(vel).max() + 1e-300
+    fp = pr.device()
+    fp.set_dynamic_tree(True)
+    fp.tree_build(ext[0], ext[1], ext[2], pr.force_soft)
+    T = O.Tree(pr.ic["pos"].copy(), vel, pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0, extent=ext)
+    old = 0.2 + 3.0 * rng.random(n)
+    fp.set_field(B.F_OLDACC, old)
+    tab = O.ewald_table(pr.box) if periodic else None
+    nsub = int(rng.integers(1, 4))
+    for _ in range(nsub):
+        k = int(rng.integers(0, n + 1))
+        act = np.sort(rng.choice(n, k, replace=False)).astype(np.int32)
+        dv = 0.2 * vscale * rng.standard_normal((k, 3))
+        T.vel[act] += dv
+        fp.set_field(B.F_VEL, T.vel)
+        if k:
+            T.kick_nodes(act, dv)
+            fp.tree_kick_nodes(act, dv)
+        dt = float(rng.uniform(0.0005, 0.01)) * ln / vscale
+        T.pos += T.vel * dt
+        T.drift_nodes(dt)
+        fp.set_field(B.F_POS, T.pos)
+        fp.tree_substep(dt)
+        m = int(rng.integers(1, n + 1))
+        tg = np.sort(rng.choice(n, m, replace=False)).astype(np.int32)
+        theta = float(rng.choice([0.0, 0.6]))
+        fp.set_active(tg)
+        fp.gravity(pr.g_grav(theta), B.WALK_NEWTON_EWALD if periodic else B.WALK_NEWTON)
+        oa, oc = T.gravity(pr.o_grav(theta), tg, old)
+        if periodic:
+            T.gravity_ewald_add(pr.o_grav(theta), tab, tg, old, oa, oc)
+        assert np.array_equal(fp.get_field(B.F_GRAVCOST)[tg], oc), "gravity counts on the kept tree"
+        assert np.abs(fp.get_field(B.F_GRAVACCEL)[tg] - oa).max() < 1e-10 * (np.abs(oa).max() + 1e-300), \
+            "gravity on the kept tree"
+        fp.set_active(None)
+    fp.close()
+    return nsub
 
 
 if __name__ == "__main__":
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0 = time.time()
     bad = 0
-    for seed in range(1000, 1000 + nseeds):
+    for seed in range(first, first + nseeds):
         try:
             info = one(seed)
             print("seed %d ok %s" % (seed, info), flush=True)
