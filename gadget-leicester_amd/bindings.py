@@ -328,7 +328,10 @@ class ForcePath:
 
     def _chk(self, rc):
         if rc != 0:
-            raise GhipError(rc, self.L.ghip_last_error(self.h).decode())
+            e = GhipError(rc, self.L.ghip_last_error(self.h).decode())
+            if GHIP_ERRORS.get(rc) == "GHIP_ETIMESTEP":   # (also when a deferred kick reports late)
+                e.endrun = self.L.ghip_timestep_endrun_code(self.h)
+            raise e
 
     # ---- data ----
     def set_counts(self, n, ngas):

@@ -2106,3 +2106,161 @@ def test_gravity_tree_with_TreeReconstructFlag_zero_walks_the_kept_tree(comoving
     Tn = O.Tree(P["Pos"].copy(), P["Vel"].copy(), pr.ic["mass"], pr.ic["type"], pr.force_soft, extent=pr.extent)
     assert np.array_equal(P["GravCost"].astype(np.int64), oracle_gravity(Tn, 0.0, everybody, old)[1])
     host.close()
+
+
+def _one_bin_steps(pr, B, nsteps, async_mode):
+    """run.c's loop with everybody in one bin on a fresh device: drift, tree build, both walks, density,
+    hmax, hydro, post-pass, kick.  async_mode: nothing waits for the host inside a step and the
+    statistics are kept on the device (ghip_set_async, ghip_run_begin ... ghip_run_end)."""
+    n, box = pr.n, pr.box
+    bin_, tb = 20, 1.0e-3 / (1 << 20)
+    soft = pr.force_soft / 2.8
+    par = dict(Timebase_interval=tb, ComovingIntegrationOn=0, Time=1.0, hubble_a=1.0,
+               ErrTolIntAccuracy=1.0e3, CourantFac=1.0e3, MaxSizeTimestep=1.0e-3, MinSizeTimestep=0.0,
+               dt_displacement=1.0, MinEgySpec=0.0, TimeBinActive=0xffffffff, logTimeBegin=0.0,
+               logTimeMax=0.0)
+    fp = pr.device()
+    zero_i = np.zeros(n, np.int32)
+    for fid in (B.F_TIMEBIN, B.F_TI_BEGSTEP, B.F_TI_CURRENT):
+        fp.set_field(fid, zero_i)
+    fp.set_field(B.F_OLDACC, np.zeros(n))
+    ext = (np.zeros(3), np.full(3, 0.5 * box), box)
+    dp = pr.g_dens()
+    dp.Timebase_interval = tb
+    per_step = []
+    if async_mode:
+        fp.set_async(True)
+        fp.run_begin(nsteps)
+    for step in range(nsteps):
+        ti = step << bin_
+        par["Ti_Current"] = ti
+        dp.Ti_Current = ti
+        if async_mode:
+            fp.step_begin()
+        fp.drift(ti, tb, box_wrap=True, boxsize=box)
+        fp.tree_build(ext[0], ext[1], ext[2], pr.force_soft)
+        fp.gravity(pr.g_grav(pr.theta if step == 0 else 0.0), B.WALK_NEWTON_EWALD)
+        fp.density(dp)
+        fp.update_hmax()
+        fp.hydro(pr.g_hydro())
+        fp.gravity_finish(pr.G)
+        fp.advance_timesteps(_fill(B.KickParams(), par, soft), counts=not async_mode)
+        if async_mode:
+            fp.step_end()
+        else:
+            per_step.append(fp.stats())
+    run = fp.run_end() if async_mode else None
+    state = {k: fp.get_field(f) for k, f in (("pos", B.F_POS), ("vel", B.F_VEL), ("hsml", B.F_HSML),
+                                             ("entropy", B.F_ENTROPY), ("acc", B.F_GRAVACCEL),
+                                             ("cost", B.F_GRAVCOST), ("hydro", B.F_HYDROACCEL),
+                                             ("timebin", B.F_TIMEBIN), ("oldacc", B.F_OLDACC))}
+    counts = fp.timebin_counts()
+    fp.close()
+    return state, per_step, run, counts
+
+
+@pytest.mark.gpu
+def test_steps_that_never_wait_for_the_host_leave_the_state_of_the_waiting_steps():
+    """ghip_set_async + the run statistics (ghip_run_begin / ghip_step_begin / ghip_step_end /
+    ghip_run_end) + the tree build that does not wait for its node counts: four resident steps enqueued
+    without a host wait leave bit for bit the state of the same steps with a synchronisation after
+    every call, and the device-side totals of the run are the sums of the per-step statistics."""
+    B = bindings()
+    pr = Problem(ng=12, gas=True, periodic=1)
+    nsteps = 4
+    s0, per_step, _, c0 = _one_bin_steps(pr, B, nsteps, False)
+    s1, _, run, c1 = _one_bin_steps(pr, B, nsteps, True)
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+    assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1]) and c0[0].sum() == pr.n
+    assert run["steps"] == nsteps and run["steps_timed"] == nsteps
+    for k in ("grav_interactions", "ewald_interactions", "dens_neighbours", "hydro_pairs", "grav_wave_steps"):
+        assert run[k] == sum(s[k] for s in per_step) > 0, k
+    assert run["launches"] > 50 * nsteps and run["ms_steps_device"] > 0 and run["ms_grav"] > 0
+    # the only host waits left inside a step: the h iteration's unconverged counts and the two tree checks
+    assert run["blocking_syncs"] <= 8 * nsteps
+
+
+@pytest.mark.gpu
+def test_errors_of_an_asynchronous_drift_and_kick_surface_at_the_next_synchronisation():
+    """Under ghip_set_async the drift and the kick return before the device has run them: a particle
+    ahead of the drift target (endrun(12), predict.c:148) and a failed timestep criterion (endrun(888),
+    timestep.c:171) are reported by the next call that synchronises, with the code the synchronous call
+    returns."""
+    B = bindings()
+    pr = Problem(ng=8, gas=True, periodic=1)
+    n = pr.n
+    fp = pr.device()
+    tic = np.zeros(n, np.int32)
+    tic[7] = 100                                    # already at time 100: a drift to 50 goes backwards
+    fp.set_field(B.F_TI_CURRENT, tic)
+    fp.set_field(B.F_TI_BEGSTEP, np.zeros(n, np.int32))
+    fp.set_field(B.F_TIMEBIN, np.zeros(n, np.int32))
+    with pytest.raises(B.GhipError):
+        fp.drift(50, 1e-6)                          # synchronous: the call itself fails
+    fp.set_field(B.F_TI_CURRENT, tic)
+    fp.set_async(True)
+    fp.drift(50, 1e-6)                              # returns at once
+    with pytest.raises(B.GhipError) as e:
+        fp.sync()
+    assert "drift" in str(e.value)
+    # the kick: a time step that does not fit the rest of the timeline (timestep.c:171: endrun(888))
+    fp.set_field(B.F_TI_CURRENT, np.zeros(n, np.int32))
+    st, par, _ = _kick_case(pr, False)
+    par["Ti_Current"] = (1 << 29) - 1               # one tick before the end of the timeline
+    soft = pr.force_soft / 2.8
+    hfull = pr.hsml0.copy()
+    hfull[:pr.ngas] = st["hs"]
+    for fid, arr in ((B.F_GRAVACCEL, st["grav"]), (B.F_HYDROACCEL, st["hyd"]), (B.F_MAXSIGNALVEL, st["vsig"]),
+                     (B.F_DENSITY, st["dens"]), (B.F_PRESSURE, st["pres"]), (B.F_HSML, hfull),
+                     (B.F_ENTROPY, st["entropy"]), (B.F_DTENTROPY, st["dtentropy"]),
+                     (B.F_TIMEBIN, st["timebin"]), (B.F_TI_BEGSTEP, st["ti_begstep"])):
+        fp.set_field(fid, arr)
+    fp.advance_timesteps(_fill(B.KickParams(), par, soft), counts=False)      # returns at once
+    with pytest.raises(B.GhipError) as e:
+        fp.sync()
+    assert e.value.endrun in (888, 818, 112313)
+    fp.close()
+
+
+@pytest.mark.gpu
+def test_a_tree_that_outgrows_the_buffers_of_the_last_build_is_rebuilt_and_its_walks_replayed():
+    """A steady-state tree build does not wait for its node count: buffers and grids are sized for what
+    the last build of the same particle number needed (+ 1/16).  Here the particles go from a jittered
+    lattice to a clustered sphere between two builds -- several times the nodes: the device marks the
+    tree unusable (every consumer then does nothing), the next entry point that synchronises rebuilds it
+    with exact sizes and replays the gravity calls made in between.  The caller sees the oracle's counts."""
+    B = bindings()
+    ic = ics.make_plummer(6000, seed=3, a=0.02, gas_fraction=0.3)
+    pr = Problem(ic=ic, periodic=0)
+    n = pr.n
+    rng = np.random.default_rng(8)
+    m = int(round(n ** (1 / 3))) + 1
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    lo, ln = pr.extent[0], pr.extent[2]
+    lattice = lo + (g + 0.5 + 0.05 * rng.standard_normal((n, 3))) * (ln / m)
+    fp = pr.device()
+    fp.set_field(B.F_POS, lattice)
+    ext = (pr.extent[0], pr.extent[1], pr.extent[2], pr.force_soft)
+    fp.tree_build(*ext)
+    nodes_lattice = fp.stats()["tree_nodes"]
+    fp.tree_build(*ext)                              # (a second build of the same shape: steady state)
+    fp.set_field(B.F_POS, pr.ic["pos"])              # the clustered sphere
+    old = 0.5 + rng.random(n)
+    fp.set_field(B.F_OLDACC, old)
+    fp.tree_build(*ext)                              # does not wait; the lattice's buffers are too small
+    fp.gravity(pr.g_grav(0.0), B.WALK_NEWTON)        # walks an empty tree, is logged
+    T = pr.oracle_tree()
+    tg = np.arange(n, dtype=np.int32)
+    oa, oc = T.gravity(pr.o_grav(0.0), tg, old)
+    assert T.numnodes > 1.3 * nodes_lattice          # (what made the buffers too small)
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), oc)
+    assert relerr(fp.get_field(B.F_GRAVACCEL), oa) < TOL
+    assert fp.stats()["tree_nodes"] == T.numnodes
+    # ... and SPH on the rebuilt gas tree
+    fp.density(pr.g_dens())
+    act = np.arange(pr.ngas, dtype=np.int32)
+    od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                   pr.hsml0)
+    assert relerr(fp.get_field(B.F_DENSITY), od["density"][:pr.ngas]) < TOL
+    fp.close()
