@@ -475,6 +475,36 @@ __global__ void k_soa_to_aos(size_t n, int ncomp, const T *__restrict__ src, T *
     dst[i * ncomp + c] = src[(size_t) c * n + i];
 }
 
+// is every record of the gas block [0, ngas) still gas?  (allvars.h:1384 holds after a
+// rearrange_particle_sequence(); a particle converted since keeps its place with another Type)
+__global__ void k_check_gas_types(int ngas, const int *__restrict__ type, int *word)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < ngas && type[i] != 0)
+    *word = 1;
+}
+
+int ghip_check_gas_types(ghip_ctx *ctx)
+{
+  bool mixed = false;
+  if(ctx->ngas > 0)
+    {
+      int *w = ghip_gas_mixed_word(ctx);
+      *w = 0;
+      k_check_gas_types<<<cdiv(ctx->ngas, 256), 256, 0, ctx->stream>>>(ctx->ngas, P<int>(ctx->f[GHIP_F_TYPE]), w);
+      HIPCHK(hipGetLastError());
+      HIPCHK(ghip_stream_sync(ctx, ctx->stream));
+      mixed = *reinterpret_cast<volatile int *>(w) != 0;
+    }
+  if(mixed != ctx->gas_mixed)
+    {
+      ctx->gas_mixed = mixed;
+      ctx->st.built = false;
+      ctx->gas_list_dirty = true;
+    }
+  return GHIP_OK;
+}
+
 extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
 {
   if(ctx)
@@ -503,6 +533,8 @@ extern "C" int ghip_set_field(ghip_ctx *ctx, int field, const void *host)
       ctx->gt.built = false;
       ctx->st.built = false;
     }
+  if(field == GHIP_F_TYPE)
+    GCHK(ghip_check_gas_types(ctx));
   return GHIP_OK;
 }
 
@@ -771,6 +803,8 @@ extern "C" int ghip_upload_aos(ghip_ctx *ctx, const void *Pp, const void *Sp, co
   ctx->gt.built = false;
   ctx->st.built = false;
   ctx->gas_wait_upload = false;
+  ctx->gas_mixed = lay->p_type >= 0 && *reinterpret_cast<volatile int *>(ghip_gas_mixed_word(ctx)) != 0;
+  ctx->gas_list_dirty = true;
   return GHIP_OK;
 }
 
@@ -794,6 +828,8 @@ extern "C" int ghip_upload_aos_particles(ghip_ctx *ctx, const void *Pp, const gh
   ctx->gt.built = false;
   ctx->st.built = false;
   ctx->gas_wait_upload = ngas > 0;   // (whatever joins in between must leave the gas tree deferred)
+  ctx->gas_mixed = lay->p_type >= 0 && *reinterpret_cast<volatile int *>(ghip_gas_mixed_word(ctx)) != 0;
+  ctx->gas_list_dirty = true;
   return GHIP_OK;
 }
 

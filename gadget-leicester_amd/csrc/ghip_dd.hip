@@ -1005,7 +1005,7 @@ __global__ void k_ghost_pack(int nrec, const int *__restrict__ list, int n, int 
                              const double *__restrict__ pres, const double *__restrict__ rho,
                              const double *__restrict__ dhf, const double *__restrict__ divv,
                              const double *__restrict__ curl, const int *__restrict__ timebin,
-                             GhostRec *__restrict__ out)
+                             const int *__restrict__ type, GhostRec *__restrict__ out)
 {
   int a = blockIdx.x * blockDim.x + threadIdx.x;
   if(a >= nrec)
@@ -1015,7 +1015,7 @@ __global__ void k_ghost_pack(int nrec, const int *__restrict__ list, int n, int 
   r.p[0] = pos[i];
   r.p[1] = pos[(size_t) n + i];
   r.p[2] = pos[2 * (size_t) n + i];
-  r.p[3] = mass[i];
+  r.p[3] = type[i] == 0 ? mass[i] : -1.0;   // (a converted particle of the gas block: nobody's neighbour)
   r.p[4] = velpred[i];
   r.p[5] = velpred[(size_t) ngas + i];
   r.p[6] = velpred[2 * (size_t) ngas + i];
@@ -1044,7 +1044,8 @@ static int pack_ghosts(ghip_ctx *ctx, int total)
     P<double>(ctx->f[GHIP_F_VELPRED]), P<double>(ctx->f[GHIP_F_HSML]),
     P<double>(ctx->f[GHIP_F_PRESSURE]), P<double>(ctx->f[GHIP_F_DENSITY]),
     P<double>(ctx->f[GHIP_F_DHSMLFAC]), P<double>(ctx->f[GHIP_F_DIVVEL]),
-    P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<GhostRec>(D.gh_send));
+    P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<int>(ctx->f[GHIP_F_TYPE]),
+    P<GhostRec>(D.gh_send));
   HIPCHK(hipGetLastError());
   return GHIP_OK;
 }
@@ -1647,6 +1648,7 @@ static int migrate_step(ghip_ctx *ctx)
       ctx->st.built = false;
       ctx->nactive = -1;
       ctx->lists_dirty = ctx->gas_list_dirty = true;
+      ctx->gas_types_unknown = true;   // (an arrival may be a converted particle of its old gas block)
       return GHIP_OK;
     }
   return ghip_fail(ctx, GHIP_EINVAL, "ghip_dd_step: migration has no phase %d", D.phase);

@@ -149,7 +149,7 @@ k_sink_density(int ns, const int *__restrict__ slot, const SinkRec *__restrict__
             continue;
           const double *r8 = gp + (size_t) 8 * p;
           const double mass_j = r8[3];
-          if(mass_j == 0)   // density.c:831-834
+          if(mass_j <= 0)   // density.c:831-834; < 0: a converted particle of the gas block, not gas
             continue;
           const double dx = d_sink_wrap(px - r8[0], b), dy = d_sink_wrap(py - r8[1], b),
                        dz = d_sink_wrap(pz - r8[2], b);

@@ -117,12 +117,14 @@ __device__ __forceinline__ BucketBox d_bucket_box(bool valid, double px, double 
 
 // mask of the staged candidates (lane l holds candidate l) that can be within max(hmax, hj) of
 // any target of the bucket
+// (jm < 0: a record of the gas block that is not gas any more -- a particle converted since the last
+// rearrange_particle_sequence(), marked by k_mark_converted -- is nobody's neighbour, ngb.c:213, 93)
 __device__ __forceinline__ unsigned long long d_cull_batch(const BucketBox &B, bool staged, double jx,
-                                                            double jy, double jz, double hj,
+                                                            double jy, double jz, double jm, double hj,
                                                             const BoxK b)
 {
   const double H = B.hmax > hj ? B.hmax : hj;
-  bool pass = staged && fabs(d_wrap(jx - B.cx, b)) <= B.ex + H &&
+  bool pass = staged && jm >= 0 && fabs(d_wrap(jx - B.cx, b)) <= B.ex + H &&
               fabs(d_wrap(jy - B.cy, b)) <= B.ey + H && fabs(d_wrap(jz - B.cz, b)) <= B.ez + H;
   return __builtin_amdgcn_ballot_w64(pass);
 }
@@ -336,7 +338,7 @@ k_density(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, c
       const int skip = N[10], pidx = N[11], pstart = N[12], pcount = N[13];
       if(pidx >= 0)
         {
-          if((batch++ % nsub) == sub)
+          if((batch++ % nsub) == sub && gp[(size_t) 8 * pidx + 3] >= 0)
             d_density_pair(gp + (size_t) 8 * pidx, valid && cs == 0, px, py, pz, vx, vy, vz, h2, hinv,
                            hinv3, hinv4, h3, b, A);
           e = e + 1;
@@ -363,7 +365,7 @@ k_density(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, c
                             sh[lane][0] = c0;
                             sh[lane][1] = src[1];
                           }
-                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, 0.0, b);
+                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c0.w, 0.0, b);
                         __syncthreads();
                         while(live)
                           {
@@ -945,6 +947,8 @@ __global__ void k_ngb_find(int nelem, const double4 *__restrict__ cl, const int4
           if(pairs && r8[7] > dist)
             dist = r8[7];
           e = e + 1;
+          if(r8[3] < 0)   // converted: P[p].Type > 0 (ngb.c:213)
+            continue;
           double dx = d_ngb_periodic(r8[0] - cx, b.periodic, b.boxsize, b.boxhalf);
           if(dx > dist)
             continue;
@@ -1179,7 +1183,7 @@ k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, con
       const int skip = N[10], pidx = N[11], pstart = N[12], pcount = N[13];
       if(pidx >= 0)
         {
-          if((batch++ % nsub) == sub)
+          if((batch++ % nsub) == sub && gp[(size_t) 8 * pidx + 3] >= 0)
             {
               const double *qs = gq + (size_t) 8 * pidx;
               const HydCand C = d_hydro_candidate(qs[0], qs[1], gp[(size_t) 8 * pidx + 7], qs[3], qs[4],
@@ -1225,7 +1229,7 @@ k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, con
                             sh[lane][3] = q1;
                           }
                         // (pairs: the candidate's own smoothing length c1.w counts too, hydra.c:1266)
-                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c1.w, b);
+                        unsigned long long live = d_cull_batch(BB, staged, c0.x, c0.y, c0.z, c0.w, c1.w, b);
                         __syncthreads();
                         while(live)
                           {

@@ -1519,6 +1519,11 @@ __global__ void k_gather_gas_local(int nsrc, int ng, const int *__restrict__ per
 int ghip_dd_build_gas_tree(ghip_ctx *ctx)
 {
   DDState &D = ctx->dd;
+  if(ctx->gas_types_unknown)
+    {
+      ctx->gas_types_unknown = false;
+      GCHK(ghip_check_gas_types(ctx));
+    }
   const int n = ctx->n, ng = ctx->ngas, nghost = D.nghost, nsg = ng + nghost;
   hipStream_t st = ctx->stream;
   TreeDev &t = ctx->st;
@@ -1576,6 +1581,8 @@ int ghip_dd_build_gas_tree(ghip_ctx *ctx)
     k_place_ghosts<<<cdiv(nsg, 256), 256, 0, st>>>(nsg, ng, P<int>(t.perm), P<GhostRec>(D.gh_recv),
                                                   P<double>(ctx->gp), P<double>(ctx->gq));
   HIPCHK(hipGetLastError());
+  t.n = nsg;
+  GCHK(ghip_mark_converted_gas(ctx));   // (a ghost that is converted on its owner arrives marked)
   // curve order of the sources (the targets are selected from it): leading digits of the
   // Peano-Hilbert key of the tree-order positions, as curve_order does for the gravity tree
   GCHK(ghip_ensure(ctx, t.phorder, (size_t) nsg * 4));
@@ -1660,6 +1667,7 @@ static int build_gas_tree(ghip_ctx *ctx, bool async)
     P<double>(ctx->f[GHIP_F_CURLVEL]), P<int>(ctx->f[GHIP_F_TIMEBIN]), P<double>(ctx->gp),
     P<double>(ctx->gq));
   HIPCHK(hipGetLastError());
+  GCHK(ghip_mark_converted_gas(ctx));
   GCHK(gas_curve_order(ctx));
   ctx->gas_list_dirty = true;
   ctx->stats.gastree_nodes = S.nnodes;
@@ -1775,6 +1783,45 @@ __global__ void k_flag_local(int n, int limit, const int *__restrict__ perm, int
     flags[s] = perm[s] < limit ? 1 : 0;
 }
 
+// A record of the gas block [0, ngas) whose Type is not 0 any more (a particle converted since the last
+// rearrange_particle_sequence(): the reference rearranges at domain decompositions only, domain.c:128,
+// and its loops test P[].Type) is neither an SPH target (density.c:1049, hydra.c:184) nor anybody's
+// neighbour (ngb.c:93, 213).  It stays in the gas tree; its record is marked with a negative mass, which
+// the neighbour loops skip, and the target lists leave it out.
+__global__ void k_mark_converted(int nsrc, int ngas, const int *__restrict__ perm, const int *__restrict__ type,
+                                 double *__restrict__ gp)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= nsrc)
+    return;
+  const int i = perm[s];
+  if(i < ngas && type[i] != 0)
+    gp[(size_t) 8 * s + 3] = -1.0;
+}
+
+__global__ void k_unflag_converted(int n, int limit, const int *__restrict__ perm, const int *__restrict__ type,
+                                   int *__restrict__ flags)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  const int i = perm[s];
+  if(i < limit && type[i] != 0)
+    flags[s] = 0;
+}
+
+int ghip_mark_converted_gas(ghip_ctx *ctx)
+{
+  TreeDev &t = ctx->st;
+  if(!ctx->gas_mixed || t.n == 0 || ctx->ngas == 0)
+    return GHIP_OK;
+  const int wg = ghip_wg(ctx);
+  k_mark_converted<<<cdiv(t.n, wg), wg, 0, ctx->stream>>>(t.n, ctx->ngas, P<int>(t.perm),
+                                                          P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->gp));
+  HIPCHK(hipGetLastError());
+  return GHIP_OK;
+}
+
 // target lists: tree-order positions of the active particles, ascending (so that 64
 // consecutive targets are spatial neighbours), sliced for this rank's shard
 static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, int *count)
@@ -1786,7 +1833,8 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
     return GHIP_OK;
   GCHK(ghip_ensure(ctx, list, (size_t) n * 4));
   const bool imports = n > host_limit;   // multi-GPU: sources beyond the local particles are never targets
-  if(ctx->nactive < 0 && !imports)
+  const bool mixed = (&t == &ctx->st) && ctx->gas_mixed;   // converted particles in the gas block: no targets
+  if(ctx->nactive < 0 && !imports && !mixed)
     {
       HIPCHK(hipMemcpyAsync(list.p, t.phorder.p, (size_t) n * 4, hipMemcpyDeviceToDevice, st));
       *count = n;
@@ -1805,6 +1853,9 @@ static int make_list(ghip_ctx *ctx, TreeDev &t, int host_limit, DevBuf &list, in
                                                               P<int>(t.iperm), host_limit,
                                                               P<int>(ctx->dflags));
     }
+  if(mixed)
+    k_unflag_converted<<<cdiv(n, 256), 256, 0, st>>>(n, host_limit, P<int>(t.perm), P<int>(ctx->f[GHIP_F_TYPE]),
+                                                    P<int>(ctx->dflags));
   // flags in Peano-Hilbert order, then an order-preserving selection of the PH-ordered indices
   k_gather_i32<<<cdiv(n, 256), 256, 0, st>>>(n, P<int>(t.phorder), P<int>(ctx->dflags),
                                              P<int>(ctx->dtgt_a));

@@ -2264,3 +2264,64 @@ def test_a_tree_that_outgrows_the_buffers_of_the_last_build_is_rebuilt_and_its_w
                    pr.hsml0)
     assert relerr(fp.get_field(B.F_DENSITY), od["density"][:pr.ngas]) < TOL
     fp.close()
+
+
+@pytest.mark.gpu
+def test_converted_particles_in_the_gas_block_are_neither_sph_targets_nor_neighbours():
+    """Between two domain decompositions a gas particle that became a sink or a star keeps its place in the
+    gas block [0, N_gas) with another Type: the reference rearranges the particle sequence only at
+    decompositions (domain.c:128; sfr_eff.c:919 "N_gas is only reduced once rearrange_particle_sequence
+    is called"), and until then its loops test P[].Type -- no SPH target (density.c:1049, hydra.c:184),
+    nobody's neighbour (ngb.c:93, 213), still a gravity source and target.  Same here: densities,
+    neighbour numbers, hydro accelerations and pair counts of the remaining gas equal the oracle's, the
+    converted records keep their SPH fields, gravity counts are exact."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    rng = np.random.default_rng(12)
+    conv = np.sort(rng.choice(ng, 25, replace=False))
+    typ = pr.ic["type"].copy()
+    typ[conv[:15]] = 5                      # BH_FORM: gas -> sink
+    typ[conv[15:]] = 4                      # SFR: gas -> star
+    pr.ic["type"] = typ
+    gas = np.setdiff1d(np.arange(ng), conv).astype(np.int32)
+    fp = pr.device()                        # (uploads the types: the gas block is found mixed)
+    sentinel = np.full(ng, -7.0)
+    fp.set_field(B.F_DENSITY, sentinel)
+    pr.device_tree(fp)
+    T = pr.oracle_tree()
+    tg = np.arange(n, dtype=np.int32)
+    fp.gravity(pr.g_grav(pr.theta), B.WALK_NEWTON_EWALD)
+    a0, c0 = T.gravity(pr.o_grav(pr.theta), tg, np.zeros(n))
+    T.gravity_ewald_add(pr.o_grav(pr.theta), O.ewald_table(pr.box), tg, np.zeros(n), a0, c0)
+    assert np.array_equal(fp.get_field(B.F_GRAVCOST), c0)
+    fp.density(pr.g_dens())                 # "everybody active"
+    od = T.density(pr.o_dens(), gas, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                   pr.hsml0)
+    dens = fp.get_field(B.F_DENSITY)
+    assert relerr(dens[gas], od["density"][gas]) < TOL
+    assert relerr(fp.get_field(B.F_HSML)[gas], od["hsml"][gas]) < TOL
+    assert np.abs(fp.get_field(B.F_NUMNGB)[gas] - od["numngb"][gas]).max() < 1e-10
+    assert np.array_equal(dens[conv], sentinel[conv])               # not evaluated
+    assert fp.stats()["dens_neighbours"] == od["ngb_visits"]
+    fp.update_hmax()
+    fp.hydro(pr.g_hydro())
+    T.update_hmax(gas, od["hsml"], od["divvel"])
+    oh = T.hydro(pr.o_hydro(), gas, pr.velpred, od["hsml"], od["density"], od["pressure"], od["dhsmlfac"],
+                 od["divvel"], od["curlvel"], pr.timebin)
+    assert fp.stats()["hydro_pairs"] == oh["npairs"]
+    ha = fp.get_field(B.F_HYDROACCEL)
+    assert np.abs(ha[gas] - oh["hydroaccel"][gas]).max() < TOL * np.abs(oh["hydroaccel"][gas]).max()
+    # the same decomposition-free state with an explicit active list that still names the converted ones
+    fp.set_active(np.arange(0, n, 3, dtype=np.int32))
+    fp.set_field(B.F_DENSITY, sentinel)
+    fp.density(pr.g_dens())
+    sub = gas[gas % 3 == 0]
+    od2 = T.density(pr.o_dens(), sub, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                    od["hsml"])
+    d2 = fp.get_field(B.F_DENSITY)
+    assert relerr(d2[sub], od2["density"][sub]) < TOL
+    assert np.array_equal(d2[conv], sentinel[conv])
+    # back to a pure gas block (after a rearrangement): the fast paths again
+    fp.set_field(B.F_TYPE, np.where(np.arange(n) < ng, 0, pr.ic["type"]).astype(np.int32))
+    fp.close()
