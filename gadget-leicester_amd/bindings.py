@@ -186,7 +186,7 @@ EXPORTS = [
     "ghip_dd_init", "ghip_dd_set_domain", "ghip_dd_set_splits", "ghip_dd_set_segments", "ghip_dd_keys", "ghip_dd_find_split",
     "ghip_set_dynamic_tree", "ghip_tree_substep", "ghip_tree_kick_nodes", "ghip_tree_kick_nodes_vmax",
     "ghip_tree_dump_dynamic",
-    "ghip_gas_block_mixed", "ghip_set_hydro_release", "ghip_download_aos_async",
+    "ghip_gas_block_mixed", "ghip_set_massless_gas_rule", "ghip_set_hydro_release", "ghip_download_aos_async",
     "ghip_gravity_to_records", "ghip_pin_host", "ghip_unpin_host", "ghip_dd_set_ghost_margin", "ghip_dd_rccl_unique_id", "ghip_dd_rccl_connect",
     "ghip_dd_rccl_library", "ghip_dd_begin", "ghip_dd_step", "ghip_dd_exchange",
     "ghip_dd_exchange_local", "ghip_dd_exchange_host", "ghip_dd_run", "ghip_dd_get_info",
@@ -603,6 +603,9 @@ class ForcePath:
         return out
 
     # ---- sub-steps on the tree of the last full build (forcetree.c:1356-1651) ----
+    def set_massless_gas_rule(self, rule=3):
+        self._chk(self.L.ghip_set_massless_gas_rule(self.h, int(rule)))
+
     def set_dynamic_tree(self, on=True):
         self._chk(self.L.ghip_set_dynamic_tree(self.h, int(bool(on))))
 

@@ -1149,6 +1149,18 @@ extern "C" int ghip_tree_build(ghip_ctx *ctx, const double corner[3], const doub
   return GHIP_OK;
 }
 
+extern "C" int ghip_set_massless_gas_rule(ghip_ctx *ctx, int on)
+{
+  if(!ctx)
+    return GHIP_EINVAL;
+  GHIP_JOIN(ctx);
+  const int rule = on == 1 ? 1 : (on ? 3 : 0);
+  if(ctx->skip_massless != rule)
+    ctx->st.built = false;   // the rule is baked into the gas records
+  ctx->skip_massless = rule;
+  return GHIP_OK;
+}
+
 extern "C" int ghip_set_adaptive_gravsoft(ghip_ctx *ctx, int on)
 {
   if(!ctx)

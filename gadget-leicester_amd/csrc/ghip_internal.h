@@ -269,6 +269,9 @@ struct ghip_ctx
   DevBuf act_host_idx;  // i32[nactive] host indices (uploaded)
   int nactive = -1;     // -1: all
   bool gas_mixed = false;        // a record of the gas block [0, ngas) has Type != 0 (ghip_check_gas_types)
+  int skip_massless = 0;         // a gas particle of mass 0 is nobody's neighbour: 1 in density() (-DDUST or
+                                 // -DBLACK_HOLES), 3 in density() and hydro_force() (-DBLACK_HOLES)
+  bool massless_marked = false;  // the gas records carry the mark of the massless rule
   bool gas_types_unknown = false;  // ... not known since a migration: checked before the next gas tree
   bool lists_dirty = true;       // gravity target list
   bool gas_list_dirty = true;    // gas target list (made once the deferred gas tree exists)
@@ -443,6 +446,7 @@ static inline unsigned long long *ghip_rslot(ghip_ctx *ctx, int kind)
 // host copy of a slot buffer added up: out[kind][which], which = 0, 1
 int ghip_read_slots(ghip_ctx *ctx, DevBuf &buf, unsigned long long out[GHIP_CK_COUNT][2]);
 int ghip_mark_converted_gas(ghip_ctx *ctx);
+int ghip_unmark_massless_for_hydro(ghip_ctx *ctx);
 int ghip_check_gas_types(ghip_ctx *ctx);   // after TYPE changed: recount, sets ctx->gas_mixed (synchronises)
 int ghip_dyn_capture(ghip_ctx *ctx);                 // after a full build: copy the gravity tree, vs / vmax per node
 int ghip_dyn_kick_recorded(ghip_ctx *ctx);           // force_kick_node for what ghip_advance_timesteps recorded

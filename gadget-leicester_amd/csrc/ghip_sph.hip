@@ -1152,7 +1152,7 @@ k_hydro(const TreeSizes *__restrict__ ts, const SphNode *__restrict__ nodes, con
       T.px = r8[0];
       T.py = r8[1];
       T.pz = r8[2];
-      T.mass = r8[3];
+      T.mass = r8[3] < 0 ? 0.0 : r8[3];   // (a swallowed target's record is marked like a dead neighbour's)
       T.vx = r8[4];
       T.vy = r8[5];
       T.vz = r8[6];
@@ -1320,6 +1320,7 @@ int ghip_hydro_impl(ghip_ctx *ctx, const ghip_hydro_params *p)
     return GHIP_OK;
   hipStream_t st = ctx->stream;
   TreeDev &t = ctx->st;
+  GCHK(ghip_unmark_massless_for_hydro(ctx));   // (-DDUST without -DBLACK_HOLES)
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
   unsigned long long *counter = ghip_cslot(ctx, GHIP_CK_HYDRO);
   HIPCHK(hipMemsetAsync(counter, 0, GHIP_CKIND_U64 * 8, st));

@@ -1615,6 +1615,7 @@ int ghip_dd_refresh_ghosts(ghip_ctx *ctx)
                                                              P<GhostRec>(D.gh_recv),
                                                              P<double>(ctx->gp), P<double>(ctx->gq));
       HIPCHK(hipGetLastError());
+      GCHK(ghip_mark_converted_gas(ctx));   // (the refreshed records arrive with their masses)
     }
   return ghip_gastree_refresh_hmax(ctx);
 }
@@ -1788,14 +1789,17 @@ __global__ void k_flag_local(int n, int limit, const int *__restrict__ perm, int
 // and its loops test P[].Type) is neither an SPH target (density.c:1049, hydra.c:184) nor anybody's
 // neighbour (ngb.c:93, 213).  It stays in the gas tree; its record is marked with a negative mass, which
 // the neighbour loops skip, and the target lists leave it out.
-__global__ void k_mark_converted(int nsrc, int ngas, const int *__restrict__ perm, const int *__restrict__ type,
-                                 double *__restrict__ gp)
+// (massless != 0, the -DBLACK_HOLES / -DDUST builds: a swallowed gas particle, Mass == 0, is skipped by
+// the neighbour loops as well -- density.c:831-834, hydra.c:1235-1238 -- while it stays a target; a ghost
+// arrives with its mass and is marked here)
+__global__ void k_mark_converted(int nsrc, int ngas, int massless, const int *__restrict__ perm,
+                                 const int *__restrict__ type, double *__restrict__ gp)
 {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if(s >= nsrc)
     return;
   const int i = perm[s];
-  if(i < ngas && type[i] != 0)
+  if((i < ngas && type[i] != 0) || (massless && gp[(size_t) 8 * s + 3] == 0))
     gp[(size_t) 8 * s + 3] = -1.0;
 }
 
@@ -1813,12 +1817,40 @@ __global__ void k_unflag_converted(int n, int limit, const int *__restrict__ per
 int ghip_mark_converted_gas(ghip_ctx *ctx)
 {
   TreeDev &t = ctx->st;
-  if(!ctx->gas_mixed || t.n == 0 || ctx->ngas == 0)
+  if((!ctx->gas_mixed && !ctx->skip_massless) || t.n == 0)
     return GHIP_OK;
   const int wg = ghip_wg(ctx);
-  k_mark_converted<<<cdiv(t.n, wg), wg, 0, ctx->stream>>>(t.n, ctx->ngas, P<int>(t.perm),
-                                                          P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->gp));
+  k_mark_converted<<<cdiv(t.n, wg), wg, 0, ctx->stream>>>(t.n, ctx->ngas, ctx->skip_massless ? 1 : 0,
+                                                          P<int>(t.perm), P<int>(ctx->f[GHIP_F_TYPE]),
+                                                          P<double>(ctx->gp));
   HIPCHK(hipGetLastError());
+  ctx->massless_marked = ctx->skip_massless != 0;
+  return GHIP_OK;
+}
+
+// -DDUST without -DBLACK_HOLES: hydro_force() sums the massless gas that density() skipped (hydra.c:1235
+// is under BLACK_HOLES alone): the mark comes off the records that are gas
+__global__ void k_unmark_massless(int nsrc, int ngas, const int *__restrict__ perm, const int *__restrict__ type,
+                                  double *__restrict__ gp)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= nsrc)
+    return;
+  const int i = perm[s];
+  if(gp[(size_t) 8 * s + 3] < 0 && (i >= ngas || type[i] == 0))
+    gp[(size_t) 8 * s + 3] = 0.0;
+}
+
+int ghip_unmark_massless_for_hydro(ghip_ctx *ctx)
+{
+  TreeDev &t = ctx->st;
+  if(!ctx->massless_marked || ctx->skip_massless != 1 || t.n == 0)
+    return GHIP_OK;
+  const int wg = ghip_wg(ctx);
+  k_unmark_massless<<<cdiv(t.n, wg), wg, 0, ctx->stream>>>(t.n, ctx->ngas, P<int>(t.perm),
+                                                           P<int>(ctx->f[GHIP_F_TYPE]), P<double>(ctx->gp));
+  HIPCHK(hipGetLastError());
+  ctx->massless_marked = false;
   return GHIP_OK;
 }
 

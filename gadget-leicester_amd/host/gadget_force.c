@@ -221,6 +221,8 @@ int gadget_force_init(const struct gadget_force_config *cfg)
   RcclConnected = 0;
   if(!RecP)
     lay_defaults();
+  /* density.c:831-834, hydra.c:1235-1238 */
+  ghip_set_massless_gas_rule(Ctx, cfg->black_holes ? 3 : (cfg->dust ? 1 : 0));
   KeptTree = 0;
   KickN = 0;
   if(cfg->dynamic_tree && ghip_set_dynamic_tree(Ctx, 1) != GHIP_OK)

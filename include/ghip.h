@@ -597,6 +597,13 @@ int ghip_gravity_direct(ghip_ctx *ctx, const ghip_grav_params *p);
 int ghip_density(ghip_ctx *ctx, const ghip_dens_params *p);
 int ghip_update_hmax(ghip_ctx *ctx);
 int ghip_hydro(ghip_ctx *ctx, const ghip_hydro_params *p);
+/* -DBLACK_HOLES / -DDUST builds: a gas particle of mass 0 (swallowed, waiting for the next
+ * rearrange_particle_sequence) is skipped by the neighbour loop of density() (rule 1: -DDUST or
+ * -DBLACK_HOLES, density.c:831-834) and also by hydro_force()'s (rule 3: -DBLACK_HOLES,
+ * hydra.c:1235-1238); it stays a target.  0 (default): the builds without these flags sum it with
+ * weight 0 but count it in NumNgb.  Independent of this switch a record of the gas block whose Type is
+ * not 0 is never a target or a neighbour, as in the reference's loops. */
+int ghip_set_massless_gas_rule(ghip_ctx *ctx, int rule);
 /* When ghip_hydro is called underneath a GHIP_WALK_NEWTON_EWALD pair in flight, its kernel is held
  * back on the device until the Ewald walk drains (fastest step for resident data).  early != 0: it
  * starts at once -- the step's kernels take 0.2 ms longer at c2, but a host that downloads the SPH

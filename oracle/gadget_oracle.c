@@ -1342,6 +1342,14 @@ int orc_ngb_treefind_pairs(const orc_tree *t, const double c[3], double h, const
 #define GAMMA_MINUS1 (GAMMA - 1)
 
 /* density.c:711-1029 density_evaluate, mode 0, plain-SPH members only */
+/* the neighbour loops skip gas of mass 0: bit 0 density() under -DBLACK_HOLES || -DDUST (density.c:831-834),
+ * bit 1 hydro_force() under -DBLACK_HOLES (hydra.c:1235-1238) */
+static int SkipMassless = 0;
+void orc_set_massless_gas_rule(int on)
+{
+  SkipMassless = on;
+}
+
 static int density_eval(const orc_tree *t, const orc_dens_params *p, const double pos[3],
                         const double vel[3], double h, int *ngblist, double out7[7])
 {
@@ -1355,6 +1363,8 @@ static int density_eval(const orc_tree *t, const orc_dens_params *p, const doubl
   for(int n = 0; n < numngb_inbox; n++)
     {
       int j = ngblist[n];
+      if((SkipMassless & 1) && t->mass[j] == 0)
+        continue;
       double dx = pos[0] - t->pos[3 * j + 0];
       double dy = pos[1] - t->pos[3 * j + 1];
       double dz = pos[2] - t->pos[3 * j + 2];
@@ -1630,6 +1640,8 @@ void orc_hydro(const orc_tree *t, const orc_hydro_params *p, int nactive, const 
         for(int nn = 0; nn < numngb; nn++)
           {
             int j = ngblist[nn];
+            if((SkipMassless & 2) && t->mass[j] == 0) /* hydra.c:1235-1238: -DBLACK_HOLES only */
+              continue;
             double dx = pos[0] - t->pos[3 * j + 0];
             double dy = pos[1] - t->pos[3 * j + 1];
             double dz = pos[2] - t->pos[3 * j + 2];

@@ -64,6 +64,7 @@ void orc_update_hmax(orc_tree *t, int nactive, const int *active, const double *
                      const double *divvel);
 /* the tree between two builds (forcetree.c:1356-1520): force_drift_node for every node,
  * force_kick_node for the kicked particles */
+void orc_set_massless_gas_rule(int on);   /* density.c:831-834, hydra.c:1235-1238 */
 void orc_tree_drift_nodes(orc_tree *t, double dt_drift, double dt_drift_hmax);
 void orc_tree_kick_nodes(orc_tree *t, int n, const int *idx, const double *dv3);
 void orc_tree_dump_dynamic(const orc_tree *t, double *s3, double *len, double *vs3, double *vmax);

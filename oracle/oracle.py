@@ -62,6 +62,7 @@ def lib():
         L.orc_tree_dump_ext.argtypes = [C.c_void_p] * 6
         L.orc_tree_dump_particles.argtypes = [C.c_void_p] * 3
         L.orc_update_hmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_massless_gas_rule.argtypes = [C.c_int]
         L.orc_tree_drift_nodes.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.orc_tree_kick_nodes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_tree_dump_dynamic.argtypes = [C.c_void_p] * 5
@@ -152,6 +153,13 @@ def ewald_force(i, j, k, x):
     f = np.zeros(3)
     lib().orc_ewald_force(i, j, k, _p(x), _p(f))
     return f
+
+
+def set_massless_gas_rule(rule):
+    """The SPH neighbour loops skip gas of mass 0: rule 1 = density() only (-DDUST without
+    -DBLACK_HOLES, density.c:831-834), 3 = density() and hydro_force() (-DBLACK_HOLES,
+    hydra.c:1235-1238), 0 = neither.  A process-wide switch of the oracle, like the compile-time flags."""
+    lib().orc_set_massless_gas_rule(int(rule))
 
 
 class Tree:

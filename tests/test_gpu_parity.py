@@ -2325,3 +2325,51 @@ def test_converted_particles_in_the_gas_block_are_neither_sph_targets_nor_neighb
     # back to a pure gas block (after a rearrangement): the fast paths again
     fp.set_field(B.F_TYPE, np.where(np.arange(n) < ng, 0, pr.ic["type"]).astype(np.int32))
     fp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule", [1, 3])
+def test_swallowed_gas_of_mass_zero_is_skipped_by_the_neighbour_loops_of_a_black_hole_build(rule):
+    """-DBLACK_HOLES / -DDUST: `if(P[j].Mass == 0) continue;` in the neighbour loop of density()
+    (density.c:831-834, either flag: rule 1) and of hydro_force() (hydra.c:1235-1238, -DBLACK_HOLES only:
+    rule 3) -- a swallowed gas particle waits with mass 0 for the next rearrangement, contributes
+    nothing and, unlike in a build without these flags, is not counted in NumNgb either; it stays an SPH
+    target itself.  ghip_set_massless_gas_rule against the oracle with the same switch."""
+    B = bindings()
+    pr = Problem(ng=10, gas=True, periodic=1)
+    n, ng = pr.n, pr.ngas
+    rng = np.random.default_rng(31)
+    gone = np.sort(rng.choice(ng, 40, replace=False))
+    mass = pr.ic["mass"].copy()
+    mass[gone] = 0.0
+    pr.ic["mass"] = mass
+    fp = pr.device()
+    fp.set_massless_gas_rule(rule)
+    O.set_massless_gas_rule(rule)
+    try:
+        pr.device_tree(fp)
+        T = pr.oracle_tree()
+        act = np.arange(ng, dtype=np.int32)
+        fp.density(pr.g_dens())
+        od = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                       pr.hsml0)
+        assert fp.stats()["dens_neighbours"] == od["ngb_visits"]
+        assert relerr(fp.get_field(B.F_HSML)[:ng], od["hsml"][:ng]) < TOL
+        assert relerr(fp.get_field(B.F_DENSITY), od["density"][:ng]) < TOL        # the swallowed ones too: targets
+        assert np.abs(fp.get_field(B.F_NUMNGB)[:ng] - od["numngb"][:ng]).max() < 1e-10
+        fp.update_hmax()
+        fp.hydro(pr.g_hydro())
+        T.update_hmax(act, od["hsml"], od["divvel"])
+        oh = T.hydro(pr.o_hydro(), act, pr.velpred, od["hsml"], od["density"], od["pressure"], od["dhsmlfac"],
+                     od["divvel"], od["curlvel"], pr.timebin)
+        assert fp.stats()["hydro_pairs"] == oh["npairs"]
+        ha = fp.get_field(B.F_HYDROACCEL)
+        assert np.abs(ha - oh["hydroaccel"][:ng]).max() < TOL * np.abs(oh["hydroaccel"]).max()
+        # the rule matters: without it the massless neighbours are counted in NumNgb
+        O.set_massless_gas_rule(0)
+        od0 = T.density(pr.o_dens(), act, pr.velpred, pr.entropy, pr.dtentropy, pr.timebin, pr.ti_begstep,
+                        pr.hsml0)
+        assert od0["ngb_visits"] != od["ngb_visits"]
+    finally:
+        O.set_massless_gas_rule(0)
+        fp.close()
