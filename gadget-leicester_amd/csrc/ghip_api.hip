@@ -177,7 +177,7 @@ static void free_buf(DevBuf &b)
 
 extern "C" const char *ghip_version(void)
 {
-  return "ghip 0.1 (gfx950)";
+  return "ghip 0.3 (gfx950)";
 }
 
 extern "C" int ghip_create(int device, ghip_ctx **out)
