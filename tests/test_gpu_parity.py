@@ -1838,7 +1838,7 @@ def test_pm_periodic_long_range_force_parity(ng, pmgrid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("periodic", [0, 1])
+@pytest.mark.parametrize("periodic", [0, 1, 2])
 def test_substeps_walk_the_drifted_and_kicked_tree_of_the_last_full_build(periodic):
     """Sub-step reuse of the tree (forcetree.c:1356-1651, force_drift_node / force_kick_node): after a
     full build, three sync points with kicks of random subsets and drifts of everybody.  The gravity
@@ -1846,8 +1846,11 @@ def test_substeps_walk_the_drifted_and_kicked_tree_of_the_last_full_build(period
     the full build, centres of mass moved with vs, sides grown by 2 vmax dt -- not those of a tree of
     the current positions: interaction counts equal the oracle's (orc_tree_drift_nodes /
     orc_tree_kick_nodes on its insertion tree) and differ from a rebuild's; the kept tree's nodes equal
-    the oracle's node by node; density() on the same sub-step is unchanged by the choice of tree."""
+    the oracle's node by node; density() on the same sub-step is unchanged by the choice of tree.
+    periodic = 2: a TreePM build -- the short-range walk (forcetree.c:2330) on the kept tree."""
     B = bindings()
+    treepm = periodic == 2
+    periodic = 1 if treepm else periodic
     pr = Problem(ng=10, gas=True, periodic=periodic)
     n, ng = pr.n, pr.ngas
     rng = np.random.default_rng(17)
@@ -1862,11 +1865,18 @@ def test_substeps_walk_the_drifted_and_kicked_tree_of_the_last_full_build(period
     fp.set_dynamic_tree(True)
     fp.tree_build(*ext)
     T = O.Tree(pos, vel, pr.ic["mass"], pr.ic["type"], pr.force_soft, hsml=pr.hsml0, extent=pr.extent)
-    tab = O.ewald_table(pr.box) if periodic else None
-    walk = B.WALK_NEWTON_EWALD if periodic else B.WALK_NEWTON
+    tab = O.ewald_table(pr.box) if (periodic and not treepm) else None
+    walk = B.WALK_SHORTRANGE if treepm else (B.WALK_NEWTON_EWALD if periodic else B.WALK_NEWTON)
     everybody = np.arange(n, dtype=np.int32)
+    asmth = 1.25 * pr.box / 16
+    sr = dict(rcut=4.5 * asmth, asmth=asmth)
+    if treepm:
+        g_grav = pr.g_grav
+        pr.g_grav = lambda theta: g_grav(theta, sr["rcut"], asmth)
 
     def oracle_gravity(tree, theta, tg, old):
+        if treepm:
+            return tree.gravity(pr.o_grav(theta, **sr), tg, old, kind="shortrange")
         a, cst = tree.gravity(pr.o_grav(theta), tg, old)
         if periodic:
             tree.gravity_ewald_add(pr.o_grav(theta), tab, tg, old, a, cst)
