@@ -474,19 +474,41 @@ static int build_plan(ghip_ctx *ctx, int kind, int nb, int ns, WalkPlan &plan, i
   GCHK(ghip_ensure(ctx, b_nsub, (size_t) nb * 4));
   GCHK(ghip_ensure(ctx, b_woff, (size_t) (nb + 1) * 4));
   GCHK(ghip_ensure(ctx, b_wave, (size_t) maxwaves * 4));
-  GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][0], (size_t) nb * 4));
-  GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][1], (size_t) nb * 4));
+  // per-bucket visits of the previous call and of this one; allocated with headroom, since growing
+  // a buffer drops what it held (the history is then simply not used for this call)
+  int cur = ctx->plan_cur[kind];
+  bool prev_kept = ctx->plan_steps[kind][cur].p != nullptr;
+  const size_t steps_bytes = ((size_t) nb + nb / 8 + 64) * 4;
+  for(int k = 0; k < 2; k++)
+    if(ctx->plan_steps[kind][k].cap < (size_t) nb * 4)
+      {
+        GCHK(ghip_ensure(ctx, ctx->plan_steps[kind][k], steps_bytes));
+        if(k == cur)
+          prev_kept = false;
+      }
   GCHK(ghip_ensure(ctx, ctx->counters, 64 * 8));
   const bool adaptive = !(getenv("GHIP_WALK_ADAPTIVE") && atoi(getenv("GHIP_WALK_ADAPTIVE")) == 0);
-  int have_prev = (adaptive && kind < 2 && ctx->plan_nb[kind] == nb && ctx->plan_ns[kind] == ns) ? 1 : 0;
-  int cur = ctx->plan_cur[kind];
+  // history of the kind's previous call: usable when that call had about as many buckets (a
+  // shard's particle number changes with every migration, the merged tree's segment count may too;
+  // neither moves the targets along the curve by more than a few buckets)
+  const int pnb = ctx->plan_nb[kind];
+  int tol = nb / 16 < 8 ? 8 : nb / 16;
+  if(getenv("GHIP_PLAN_EXACT") && atoi(getenv("GHIP_PLAN_EXACT")))
+    tol = ctx->plan_ns[kind] == ns ? 0 : -1;
+  bool have_prev = adaptive && kind < 2 && pnb > 0 && (pnb > nb ? pnb - nb : nb - pnb) <= tol && prev_kept;
+  int nprev = have_prev ? (pnb < nb ? pnb : nb) : 0;
+  if(getenv("GHIP_PLAN_DEBUG") && kind < 2)
+    {
+      static int calls[2], used[2];
+      calls[kind]++;
+      used[kind] += have_prev;
+      if(calls[kind] % 16 == 0)
+        fprintf(stderr, "ghip plan kind %d: history used in %d of %d calls (nb %d, before %d)\n", kind,
+                used[kind], calls[kind], nb, pnb);
+    }
   unsigned int *prev = P<unsigned int>(ctx->plan_steps[kind][cur]);
   unsigned int *out = P<unsigned int>(ctx->plan_steps[kind][cur ^ 1]);
-  // total of the previous call of this kind (the walk accumulates it in the kind's counter slots,
-  // which the caller clears after this -- on the same stream)
-  unsigned long long *total_prev = ghip_cslot(ctx, kind);
-  k_plan_nsub<<<cdiv(nb, 256), 256, 0, st>>>(nb, ns, sbase, prev, total_prev, have_prev,
-                                             P<int>(b_nsub));
+  k_plan_nsub<<<cdiv(nb, 256), 256, 0, st>>>(nb, ns, sbase, prev, nprev, P<int>(b_nsub));
   size_t tb = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P<int>(b_nsub),
                                           P<int>(b_woff), nb, st));

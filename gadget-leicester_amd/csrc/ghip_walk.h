@@ -906,26 +906,36 @@ k_grav_walk(int nelem, const WalkHot *__restrict__ hot, const WalkCold *__restri
 // wavefront is a serial chain of dependent loads, only their number hides the latency.  The sum
 // is bounded by S+2 per bucket on average, which is what the grid is sized for.
 __global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__restrict__ steps_prev,
-                            const unsigned long long *__restrict__ total_prev, int have_prev,
-                            int *__restrict__ nsub)
+                            int nprev, int *__restrict__ nsub)
 {
+  // nprev > 0: the previous call of the kind left the visits of its first nprev buckets (the
+  // caller passes min(nb, its bucket count): a shard's particle number moves by a few buckets
+  // from step to step, the curve order of the targets does not).  Their sum is taken here, by
+  // every block again (<= 32 loads per thread), so that sum(nsub) <= (S+2) nb holds by
+  // construction: buckets with history share S*nprev, the others get S.
+  __shared__ unsigned long long part[4];
+  unsigned long long tot = 0;
+  if(nprev > 0)
+    {
+      for(int k = threadIdx.x; k < nprev; k += blockDim.x)
+        tot += steps_prev[k];
+      for(int o = 32; o > 0; o >>= 1)
+        tot += __shfl_xor(tot, o);
+      if((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = tot;
+      __syncthreads();
+      tot = part[0] + part[1] + part[2] + part[3];
+    }
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= nb)
     return;
   int s = ns < sbase ? ns : sbase;
-  if(have_prev)
+  if(b < nprev && tot > 0)
     {
-      // element visits of the previous call of the kind: its 64 counter slots added up
-      unsigned long long tot = 0;
-      for(int k = 0; k < GHIP_CSLOTS; k++)
-        tot += total_prev[k * GHIP_CSLOT_U64 + 1];
-      double mean = (double) tot / (double) nb;
-      if(mean > 0)
-        {
-          s = (int) ((double) sbase * (double) steps_prev[b] / mean) + 1;
-          s = s < 2 ? 2 : s;
-          s = s > 64 ? 64 : s;
-        }
+      double mean = (double) tot / (double) nprev;
+      s = (int) ((double) sbase * (double) steps_prev[b] / mean) + 1;
+      s = s < 2 ? 2 : s;
+      s = s > 64 ? 64 : s;
       if(s > ns)
         s = ns;
     }
@@ -933,8 +943,8 @@ __global__ void k_plan_nsub(int nb, int ns, int sbase, const unsigned int *__res
 }
 
 // The grid and the partial-sum buffers are sized for maxwaves = (S+2)*nb + 8 wavefronts, which
-// bounds sum(nsub) only while the kind's visit counter equals the sum of steps_prev[] (both are written by
-// the same previous launch).  Should that invariant ever break, wavefronts beyond maxwaves would
+// bounds sum(nsub) because k_plan_nsub normalises with the sum of the very steps_prev[] entries it uses.
+// Should that invariant ever break, wavefronts beyond maxwaves would
 // not exist while k_combine_grav still summed their slots: the plan is therefore checked here and
 // an overflow is a hard error (GHIP_E_PLAN in the context's device error word, reported by the
 // next synchronising entry point) instead of silently wrong forces.
