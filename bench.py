@@ -316,7 +316,7 @@ def main():
     st = fp.stats()
     phase_ms = {k: rs["ms_" + k] for k in ("tree", "grav", "ewald", "dens", "hmax", "hydro")}
     work = {k: rs[k] for k in ("grav_interactions", "ewald_interactions", "dens_neighbours",
-                               "hydro_pairs", "grav_wave_steps")}
+                               "hydro_pairs", "grav_wave_steps", "ewald_wave_steps")}
     work["dens_iterations"] = rs["dens_extra_iterations"]
     work["grav_targets"] = st["grav_targets"]
     tot = [work["grav_interactions"], work["ewald_interactions"], work["dens_neighbours"],
@@ -427,7 +427,8 @@ def main():
                                     "dens_neighbours": work["dens_neighbours"] / K,
                                     "dens_extra_iterations": work["dens_iterations"] / K,
                                     "hydro_pairs": work["hydro_pairs"] / K,
-                                    "grav_wave_steps": work["grav_wave_steps"] / K},
+                                    "grav_wave_steps": work["grav_wave_steps"] / K,
+                                    "ewald_wave_steps": work["ewald_wave_steps"] / K},
         }
         if dom is not None:
             out["transport"] = transport     # "rccl": RCCL from C (ghip_dd_run); "host": staged through gloo

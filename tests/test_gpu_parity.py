@@ -465,6 +465,43 @@ def test_active_subset_and_external_targets():
     fp.set_active(None)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["newton", "ewald"])
+def test_walk_plan_history_across_calls_whose_target_count_moves_a_little(mode):
+    """The wavefront plan of a walk takes its per-bucket share from the visits of the kind's
+    previous call also when that call had a few buckets more or fewer (what migration does to a
+    shard every step): whatever the plan, forces and interaction counts stay those of the
+    reference's walk (forcetree.c:1797-2317 / :2873-3204)."""
+    B = bindings()
+    pr = Problem(ng=16, gas=True, periodic=1)     # 8192 particles = 128 buckets
+    fp = pr.device()
+    pr.device_tree(fp)
+    T = pr.oracle_tree()
+    rng = np.random.default_rng(5)
+    old = 1.0 + rng.random(pr.n)
+    fp.set_field(B.F_OLDACC, old)
+    walk = B.WALK_NEWTON if mode == "newton" else B.WALK_EWALD
+    gp, og = pr.g_grav(0.0), pr.o_grav(0.0)
+    tab = O.ewald_table(pr.box)
+    for drop in (0, 190, 70, 450, 0, 3):          # buckets: 128, 126, 127, 121, 128, 128
+        act = np.sort(rng.choice(pr.n, pr.n - drop, replace=False)).astype(np.int32)
+        fp.set_active(act if drop else None)
+        fp.set_field(B.F_GRAVACCEL, np.zeros((pr.n, 3)))
+        fp.gravity(gp, walk)
+        if mode == "newton":
+            oacc, ocost = T.gravity(og, act, old)
+        else:
+            oacc, ocost = np.zeros((len(act), 3)), np.zeros(len(act), np.int32)
+            T.gravity_ewald_add(og, tab, act, old, oacc, ocost)
+        acc = fp.get_field(B.F_GRAVACCEL)
+        assert relerr(acc[act], oacc) < TOL, drop
+        if mode == "newton":
+            assert np.array_equal(fp.get_field(B.F_GRAVCOST)[act], ocost), drop
+        else:
+            assert fp.stats()["ewald_interactions"] == int(ocost.sum()), drop
+    fp.set_active(None)
+
+
 # ------------------------------------------------------------------------------------------------
 # SPH
 # ------------------------------------------------------------------------------------------------
